@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules.
+
+Run in the build container only (the reference checkout never travels):
+
+    cd /root/repo && python oracle/gen_golden.py [--ref /root/reference]
+
+Recipe: cwd = the reference root (its sources do
+``sys.path.insert(0, './')``), bytecode writes off (the tree is read-only),
+``torchvision`` replaced by an empty module object because generator.py /
+losses.py import ``torchvision.transforms`` at module top but only use it
+under ``if __name__ == "__main__"``.  ``Encoder()`` hard-loads a weight blob
+that is absent from the checkout (.MISSING_LARGE_BLOBS), so ``torch.load`` is
+pointed at a seeded synthetic state dict while the module is constructed.
+
+Only inputs (or the seeds that make them) and the reference's outputs are
+stored -- data, not source.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+from oracle import ref_ops as R  # noqa: E402  (only for the seeded weight/input makers)
+
+
+def _import_reference(ref_root: str):
+    os.chdir(ref_root)
+    sys.path.insert(0, "./")
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    import src.models.generator as G
+    import src.models.losses as L
+    import src.models.transformer as T
+    return G, T, L
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    os.makedirs(out_dir, exist_ok=True)
+    G, T, L = _import_reference(args.ref)
+    torch.set_num_threads(8)
+
+    # ---- 1. SymmetricPadding2D ------------------------------------------------
+    x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    np.savez_compressed(
+        os.path.join(out_dir, "sympad.npz"),
+        x=_np(x),
+        pad1=_np(G.SymmetricPadding2D((1, 1, 1, 1))(x)),
+        pad2=_np(G.SymmetricPadding2D((2, 2, 2, 2))(x)),
+        pad_asym=_np(G.SymmetricPadding2D((1, 3, 0, 6))(x)),
+    )
+
+    # ---- 2. Encoder / Decoder --------------------------------------------------
+    enc_sd = R.make_encoder_state(seed=0)
+    dec_sd = R.make_decoder_state(seed=1)
+    real_load = torch.load
+    torch.load = lambda *a, **k: enc_sd
+    try:
+        enc = G.Encoder().eval()
+    finally:
+        torch.load = real_load
+    dec = G.Decoder().eval()
+    dec.load_state_dict(dec_sd)
+    assert list(dec.state_dict().keys()) == list(dec_sd.keys())
+    gen = {}
+    for name, shape, seed in (("a", (1, 3, 32, 32), 10), ("b", (2, 3, 37, 45), 11)):
+        xin = torch.rand(*shape, generator=torch.Generator().manual_seed(seed))
+        with torch.no_grad():
+            f = enc(xin)
+            y = dec(f)
+        gen[f"{name}_seed"] = np.int64(seed)
+        gen[f"{name}_shape"] = np.array(shape, dtype=np.int64)
+        gen[f"{name}_feat"] = _np(f)
+        gen[f"{name}_dec"] = _np(y)
+    # decoder gradient wrt its input and two of its weights (training needs dgrad+wgrad)
+    fin = torch.randn(1, 512, 3, 5, generator=torch.Generator().manual_seed(12)).requires_grad_(True)
+    dec.zero_grad()
+    yo = dec(fin)
+    gout = torch.randn(yo.shape, generator=torch.Generator().manual_seed(13))
+    (yo * gout).sum().backward()
+    gen["g_out"] = _np(yo)
+    gen["g_din"] = _np(fin.grad)
+    gen["g_dw28"] = _np(dec.decoder[28].weight.grad)
+    gen["g_db28"] = _np(dec.decoder[28].bias.grad)
+    gen["g_dw1_slice"] = _np(dec.decoder[1].weight.grad[:8, :16])
+    gen["g_db1"] = _np(dec.decoder[1].bias.grad)
+    gen["g_dw18_slice"] = _np(dec.decoder[18].weight.grad[:8, :16])
+    np.savez_compressed(os.path.join(out_dir, "generator.npz"), **gen)
+
+    # ---- 3. AdaIN ---------------------------------------------------------------
+    ad = {}
+    gc = torch.Generator().manual_seed(20)
+    content = torch.randn(2, 6, 7, 9, generator=gc) * 2.0 + 0.5
+    style = torch.randn(2, 6, 5, 4, generator=gc) * 0.7 - 1.0
+    gup = torch.randn(2, 6, 7, 9, generator=gc)
+    ad["content"], ad["style"], ad["gup"] = _np(content), _np(style), _np(gup)
+    for tag, lim in (("1e-5", 1e-5), ("0.1", 0.1), ("0.3", 0.3)):
+        m = T.AdaIN(eps=lim)
+        with torch.no_grad():
+            m.content_eps.fill_(4e-4)      # sqrt = 0.02  -> inside (1e-5, 0.1)
+            m.style_eps.fill_(2.5e-3)      # sqrt = 0.05
+        c = content.clone().requires_grad_(True)
+        s = style.clone().requires_grad_(True)
+        o = m(c, s)
+        (o * gup).sum().backward()
+        ad[f"out_{tag}"] = _np(o)
+        ad[f"dcontent_{tag}"] = _np(c.grad)
+        ad[f"dstyle_{tag}"] = _np(s.grad)
+        ad[f"dceps_{tag}"] = _np(m.content_eps.grad) if m.content_eps.grad is not None else np.zeros(1, np.float32)
+        ad[f"dseps_{tag}"] = _np(m.style_eps.grad) if m.style_eps.grad is not None else np.zeros(1, np.float32)
+        eps_now = m.get_current_eps()
+        ad[f"eps_{tag}"] = np.array([float(e) for e in eps_now], dtype=np.float64)
+    mean, std = T.AdaIN.calc_mean_std(content, eps=1e-5)
+    ad["mean"], ad["std"] = _np(mean), _np(std)
+    # adjust_sigmoid branches
+    ad["sig_lo"] = np.float64(float(T.AdaIN.adjust_sigmoid(torch.tensor([1e-12]), 0.3)))
+    ad["sig_hi"] = np.float64(float(T.AdaIN.adjust_sigmoid(torch.tensor([0.5]), 0.3)))
+    ad["sig_mid"] = np.float64(float(T.AdaIN.adjust_sigmoid(torch.tensor([-0.01]), 0.3)))
+    np.savez_compressed(os.path.join(out_dir, "adain.npz"), **ad)
+
+    # ---- 4. Losses ---------------------------------------------------------------
+    ls = {}
+    gl = torch.Generator().manual_seed(30)
+    a = torch.randn(2, 8, 6, 5, generator=gl)
+    b = torch.randn(2, 8, 6, 5, generator=gl) * 1.5 + 0.3
+    ls["a"], ls["b"] = _np(a), _np(b)
+
+    def fwd_grad(fn, x, *rest):
+        xx = x.clone().requires_grad_(True)
+        v = fn(xx, *rest)
+        v.backward()
+        return _np(v), _np(xx.grad)
+
+    ls["adain_style"], ls["adain_style_da"] = fwd_grad(L.AdaINStyleLoss(), a, b)
+    ls["content"], ls["content_da"] = fwd_grad(L.AdaINContentLoss(), a, b)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vin = L.VincentStyleLoss()
+    av = torch.randn(2, 8, 9, 7, generator=gl)
+    bv = torch.randn(2, 8, 9, 7, generator=gl) * 1.3
+    ls["av"], ls["bv"] = _np(av), _np(bv)
+    ls["vincent"], ls["vincent_da"] = fwd_grad(vin, av, bv)
+    mu, cov = L.VincentStyleLoss.calc_2_moments(av)
+    ls["vincent_mu"], ls["vincent_cov"] = _np(mu), _np(cov)
+    img = torch.rand(2, 3, 11, 13, generator=gl) * 3 - 1
+    ls["img"] = _np(img)
+    ls["tv"], ls["tv_dimg"] = fwd_grad(L.TVLoss(), img)
+    np.savez_compressed(os.path.join(out_dir, "losses.npz"), **ls)
+
+    # ---- 5. Histogram -------------------------------------------------------------
+    hs = {}
+    gh = torch.Generator().manual_seed(40)
+    small = torch.rand(2, 3, 24, 20, generator=gh) * 1.4 - 0.2     # <= insz, exercises clamp
+    big = torch.rand(2, 3, 150, 141, generator=gh)                  # > insz -> bilinear to 128x128
+    tgt_small = torch.rand(2, 3, 24, 20, generator=gh)
+    hs["small"], hs["big"], hs["tgt_small"] = _np(small), _np(big), _np(tgt_small)
+    for method in ("inverse-quadratic", "RBF", "thresholding"):
+        for iscale in (True, False):
+            blk = L.RGBuvHistBlock(insz=128, h=64, intensity_scale=iscale, method=method,
+                                   hist_boundary=[-3, 3], device="cpu")
+            tag = f"{method}_{int(iscale)}"
+            with torch.no_grad():
+                hs[f"hist_small_{tag}"] = _np(blk(small))
+                hs[f"hist_big_{tag}"] = _np(blk(big))
+    hl = L.HistLoss()
+    hl.histogram_block.device = "cpu"
+    hs["histloss"], hs["histloss_dsmall"] = fwd_grad(hl, small, tgt_small)
+    bigc = big.clone().requires_grad_(True)
+    v = hl(bigc, torch.rand(2, 3, 150, 141, generator=torch.Generator().manual_seed(41)))
+    v.backward()
+    hs["histloss_big"], hs["histloss_dbig"] = _np(v), _np(bigc.grad)
+    # unnormalised integer counts (thresholding, intensity_scale False): exact integers
+    blk = L.RGBuvHistBlock(insz=128, h=64, intensity_scale=False, method="thresholding",
+                           hist_boundary=[-3, 3], device="cpu")
+    with torch.no_grad():
+        hs["hist_counts_norm"] = _np(blk(small))
+    np.savez_compressed(os.path.join(out_dir, "hist.npz"), **hs)
+
+    # ---- 6. Known-answer tests ----------------------------
+    torch.manual_seed(0)
+    img = torch.rand(8, 3, 256, 256)
+    tv = float(L.TVLoss()(img))
+    torch.manual_seed(0)
+    img = torch.rand(8, 3, 256, 256)
+    tgt = torch.rand(8, 3, 256, 256)
+    with torch.no_grad():
+        hv = float(hl(img, tgt))
+    np.savez_compressed(os.path.join(out_dir, "kat.npz"), tv=np.float64(tv), histloss=np.float64(hv))
+    print("TV KAT", tv, "HistLoss KAT", hv)
+    print("golden vectors written to", out_dir)
+    for f in sorted(os.listdir(out_dir)):
+        print(f"  {f:20s} {os.path.getsize(os.path.join(out_dir, f))} bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+"""CPU: the oracle (oracle/ref_ops.py) against the reference-generated golden
+vectors in tests/golden/ (made by oracle/gen_golden.py, which imports the
+reference's own generator.py / transformer.py / losses.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+RTOL = 1e-5   # oracle and reference run the same torch ops; only op ORDER may differ
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _close(a, b, rtol=RTOL, atol=1e-6):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_sympad(golden_dir):
+    g = _load(golden_dir, "sympad.npz")
+    x = torch.from_numpy(g["x"])
+    assert np.array_equal(R.symmetric_pad(x, (1, 1, 1, 1)).numpy(), g["pad1"])
+    assert np.array_equal(R.symmetric_pad(x, (2, 2, 2, 2)).numpy(), g["pad2"])
+    assert np.array_equal(R.symmetric_pad(x, (1, 3, 0, 6)).numpy(), g["pad_asym"])
+    # pad 1 is replicate-edge, not reflect
+    assert torch.equal(R.symmetric_pad(x), torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate"))
+    assert list(R.symmetric_pad_index(5, 2, 2)) == [1, 0, 0, 1, 2, 3, 4, 4, 3]
+
+
+def test_encoder_decoder(golden_dir):
+    g = _load(golden_dir, "generator.npz")
+    enc_sd, dec_sd = R.make_encoder_state(0), R.make_decoder_state(1)
+    for name in ("a", "b"):
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        x = torch.rand(*shape, generator=torch.Generator().manual_seed(int(g[f"{name}_seed"])))
+        f = R.encoder_forward(x, enc_sd)
+        assert f.shape == g[f"{name}_feat"].shape
+        _close(f, g[f"{name}_feat"], rtol=1e-4, atol=1e-5)
+        y = R.decoder_forward(torch.from_numpy(g[f"{name}_feat"]), dec_sd)
+        _close(y, g[f"{name}_dec"], rtol=1e-4, atol=1e-5)
+    # ceil-mode pooling on odd sizes: 37x45 -> 5x6 features -> 40x48 image
+    assert g["b_feat"].shape == (2, 512, 5, 6) and g["b_dec"].shape == (2, 3, 40, 48)
+
+
+def test_decoder_grads(golden_dir):
+    g = _load(golden_dir, "generator.npz")
+    dec_sd = {k: v.clone().requires_grad_(True) for k, v in R.make_decoder_state(1).items()}
+    fin = torch.randn(1, 512, 3, 5, generator=torch.Generator().manual_seed(12)).requires_grad_(True)
+    yo = R.decoder_forward(fin, dec_sd)
+    gout = torch.randn(yo.shape, generator=torch.Generator().manual_seed(13))
+    (yo * gout).sum().backward()
+    _close(yo, g["g_out"], rtol=1e-4, atol=1e-5)
+    _close(fin.grad, g["g_din"], rtol=1e-4, atol=1e-5)
+    _close(dec_sd["decoder.28.weight"].grad, g["g_dw28"], rtol=1e-4, atol=1e-4)
+    _close(dec_sd["decoder.28.bias"].grad, g["g_db28"], rtol=1e-4, atol=1e-4)
+    _close(dec_sd["decoder.1.weight"].grad[:8, :16], g["g_dw1_slice"], rtol=1e-4, atol=1e-5)
+    _close(dec_sd["decoder.1.bias"].grad, g["g_db1"], rtol=1e-4, atol=1e-5)
+    _close(dec_sd["decoder.18.weight"].grad[:8, :16], g["g_dw18_slice"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,lim", [("1e-5", 1e-5), ("0.1", 0.1), ("0.3", 0.3)])
+def test_adain(golden_dir, tag, lim):
+    g = _load(golden_dir, "adain.npz")
+    c = torch.from_numpy(g["content"]).requires_grad_(True)
+    s = torch.from_numpy(g["style"]).requires_grad_(True)
+    ce = torch.tensor([4e-4], requires_grad=True)
+    se = torch.tensor([2.5e-3], requires_grad=True)
+    o = R.adain_forward(c, s, ce, se, lim)
+    (o * torch.from_numpy(g["gup"])).sum().backward()
+    _close(o, g[f"out_{tag}"])
+    _close(c.grad, g[f"dcontent_{tag}"], atol=1e-5)
+    _close(s.grad, g[f"dstyle_{tag}"], atol=1e-5)
+    _close(ce.grad if ce.grad is not None else torch.zeros(1), g[f"dceps_{tag}"], rtol=1e-4, atol=1e-4)
+    _close(se.grad if se.grad is not None else torch.zeros(1), g[f"dseps_{tag}"], rtol=1e-4, atol=1e-4)
+    eps = [float(R.adjust_sigmoid(se, lim)), float(R.adjust_sigmoid(ce, lim))]
+    np.testing.assert_allclose(eps, g[f"eps_{tag}"], rtol=1e-6)
+
+
+def test_adain_stats_and_sigmoid(golden_dir):
+    g = _load(golden_dir, "adain.npz")
+    mean, std = R.calc_mean_std(torch.from_numpy(g["content"]))
+    _close(mean, g["mean"]); _close(std, g["std"])
+    assert R.adjust_sigmoid(torch.tensor([1e-12]), 0.3) == g["sig_lo"] == 1e-5
+    assert R.adjust_sigmoid(torch.tensor([0.5]), 0.3) == g["sig_hi"] == 0.3
+    np.testing.assert_allclose(float(R.adjust_sigmoid(torch.tensor([-0.01]), 0.3)), g["sig_mid"], rtol=1e-6)
+
+
+def _fwd_grad(fn, x, *rest):
+    xx = x.clone().requires_grad_(True)
+    v = fn(xx, *rest)
+    v.backward()
+    return v.detach(), xx.grad
+
+
+def test_losses(golden_dir):
+    g = _load(golden_dir, "losses.npz")
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    v, d = _fwd_grad(R.adain_style_loss, a, b)
+    _close(v, g["adain_style"]); _close(d, g["adain_style_da"])
+    v, d = _fwd_grad(R.content_loss, a, b)
+    _close(v, g["content"]); _close(d, g["content_da"])
+    av, bv = torch.from_numpy(g["av"]), torch.from_numpy(g["bv"])
+    mu, cov = R.calc_2_moments(av)
+    _close(mu, g["vincent_mu"]); _close(cov, g["vincent_cov"], atol=1e-4)
+    v, d = _fwd_grad(R.vincent_style_loss, av, bv)
+    _close(v, g["vincent"], rtol=1e-4); _close(d, g["vincent_da"], rtol=1e-3, atol=1e-7)
+    img = torch.from_numpy(g["img"])
+    v, d = _fwd_grad(R.tv_loss, img)
+    _close(v, g["tv"]); _close(d, g["tv_dimg"], atol=1e-5)
+
+
+@pytest.mark.parametrize("method", ["inverse-quadratic", "RBF", "thresholding"])
+@pytest.mark.parametrize("iscale", [True, False])
+def test_hist_block(golden_dir, method, iscale):
+    g = _load(golden_dir, "hist.npz")
+    tag = f"{method}_{int(iscale)}"
+    for which in ("small", "big"):
+        h = R.rgbuv_hist(torch.from_numpy(g[which]), method=method, intensity_scale=iscale)
+        ref = g[f"hist_{which}_{tag}"]
+        assert h.shape == ref.shape == (2, 3, 64, 64)
+        if method == "thresholding" and not iscale:
+            assert np.array_equal(h.numpy(), ref)      # integer counts / integer total: bit-exact
+        else:
+            _close(h, ref, rtol=1e-5, atol=1e-9)
+
+
+def test_hist_loss(golden_dir):
+    g = _load(golden_dir, "hist.npz")
+    v, d = _fwd_grad(R.hist_loss, torch.from_numpy(g["small"]), torch.from_numpy(g["tgt_small"]))
+    _close(v, g["histloss"]); _close(d, g["histloss_dsmall"], rtol=1e-4, atol=1e-6)
+    tgt = torch.rand(2, 3, 150, 141, generator=torch.Generator().manual_seed(41))
+    v, d = _fwd_grad(R.hist_loss, torch.from_numpy(g["big"]), tgt)
+    _close(v, g["histloss_big"]); _close(d, g["histloss_dbig"], rtol=1e-4, atol=1e-6)
+
+
+def test_known_answers(golden_dir):
+    g = _load(golden_dir, "kat.npz")
+    assert float(g["tv"]) == pytest.approx(66.63690948486328, rel=1e-7)
+    assert float(g["histloss"]) == pytest.approx(2.914240598678589, rel=1e-7)
+    torch.manual_seed(0)
+    img = torch.rand(8, 3, 256, 256)
+    assert float(R.tv_loss(img)) == pytest.approx(float(g["tv"]), rel=1e-6)
+    torch.manual_seed(0)
+    img = torch.rand(8, 3, 256, 256)
+    tgt = torch.rand(8, 3, 256, 256)
+    assert float(R.hist_loss(img, tgt)) == pytest.approx(float(g["histloss"]), rel=1e-5)
+
+
+def test_loss_vgg_capture_rule():
+    """captured conv outputs are post-ReLU except the last kept layer."""
+    sd = R.make_loss_vgg_state(seed=2, upto=7)
+    x = torch.randn(1, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    f2, f7 = R.loss_vgg_features(x, sd, [2, 7])
+    assert f2.shape == (1, 64, 16, 16) and f7.shape == (1, 128, 8, 8)
+    assert float(f2.min()) >= 0.0          # idx 2 conv, overwritten by in-place ReLU idx 3
+    assert float(f7.min()) < 0.0           # idx 7 is the last kept layer: pre-ReLU
+    v = torch.randn(4, 3, 3, 3); gn = v.reshape(4, -1).norm(dim=1)
+    _close(R.weight_norm_effective(v, gn), v.numpy(), rtol=1e-6)
