@@ -1,0 +1,102 @@
+/*
+ * st_hip.h -- C ABI of libst_hip.so: hand-written CDNA4 (gfx950 / MI355X) kernels for
+ * the AdaIN style-transfer hot path of vTuanpham/Style_transfer.
+ *
+ * The reference has no FFI of its own: the hot path sits behind torch.nn.Module.__call__
+ * on contiguous NCHW fp32 tensors.  Each entry point below replaces the
+ * stock ATen op sequence of the reference lines cited next to it.  The host mirror in
+ * style_transfer_amd/ (same class names / signatures as the reference) binds these with
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous NCHW float32 unless stated;
+ *   - the caller owns all memory (inputs, outputs, workspaces); the library never
+ *     allocates, frees or keeps a pointer past the call;
+ *   - kernels are enqueued asynchronously on `stream` (a hipStream_t; 0 = null stream);
+ *   - return 0 on success, a negative ST_ERR_* otherwise; st_last_error() gives a
+ *     thread-local message.  Nothing aborts or throws across the ABI.
+ */
+#ifndef ST_HIP_H
+#define ST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* st_stream_t; /* hipStream_t */
+
+#define ST_OK 0
+#define ST_ERR_BAD_ARG (-1)   /* null pointer, non-positive or unsupported shape */
+#define ST_ERR_LAUNCH (-2)    /* hipGetLastError() after the launch was not hipSuccess */
+#define ST_ERR_UNSUPPORTED (-3)
+
+#define ST_PAD_REPLICATE 0 /* SymmetricPadding2D((1,1,1,1)) == edge replicate, generator.py:14-39 */
+#define ST_PAD_ZERO 1      /* torchvision VGG19 Conv2d(padding=1), trainer.py:168 */
+
+#define ST_POOL_FLOOR 0 /* torchvision vgg19 MaxPool2d(2,2), trainer.py:168 */
+#define ST_POOL_CEIL 1  /* MaxPool2d((2,2),(2,2),(0,0),ceil_mode=True), generator.py:53,60,73 */
+
+#define ST_HIST_INVERSE_QUADRATIC 0 /* losses.py:228-234 */
+#define ST_HIST_RBF 1               /* losses.py:221-227 */
+#define ST_HIST_THRESHOLDING 2      /* losses.py:218-220 */
+
+/* ---- library ------------------------------------------------------------------------ */
+int st_version(void);
+const char* st_last_error(void);
+
+/* ---- 3x3 convolution (MFMA implicit GEMM) ---------------------------------------------
+ * Replaces  SymmetricPadding2D((1,1,1,1)) -> nn.Conv2d(cin,cout,(3,3)) [-> nn.ReLU()]
+ * (generator.py:47-76 encoder, :89-117 decoder), optionally preceded by
+ * nn.UpsamplingNearest2d(scale_factor=2) (generator.py:92,105,112), and the zero-padded
+ * Conv2d(3x3,padding=1)+ReLU(inplace) of the torchvision VGG19 loss network
+ * (trainer.py:165-199).
+ *
+ * Weights are consumed in a packed K-major layout produced by st_conv3x3_pack_weights
+ * from the reference's OIHW nn.Parameter (the packed copy is a caller-owned cache).
+ */
+
+/* number of floats of the packed weight buffer for a cout x cin x 3 x 3 filter */
+size_t st_conv3x3_packed_elems(int cout, int cin);
+
+/* OIHW [cout][cin][3][3] -> packed.  transpose_flip = 0: forward filter.
+ * transpose_flip = 1: the data-gradient filter (in/out channels swapped, taps rotated
+ * 180 degrees); then the packed buffer describes a cin-out x cout-in filter and must be
+ * sized with st_conv3x3_packed_elems(cin, cout). */
+int st_conv3x3_pack_weights(const float* w_oihw, float* w_packed, int cout, int cin,
+                            int transpose_flip, st_stream_t stream);
+
+/* y[n][cout][H][W] = act(bias + conv3x3(pad(up(x))))   with  H = (upsample2x?2:1)*hin.
+ * x: [n][cin][hin][win].  bias may be NULL.  relu: 0/1.  pad_mode: ST_PAD_*. */
+int st_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, float* y,
+                   int n, int cin, int hin, int win, int cout,
+                   int upsample2x, int pad_mode, int relu, st_stream_t stream);
+
+/* ---- 1x1 convolution 3->3 on the raw image (generator.py:46) ------------------------- */
+int st_conv1x1_3to3_fwd(const float* x, const float* w /*[3][3]*/, const float* b /*[3]*/,
+                        float* y, int n, int hw, st_stream_t stream);
+
+/* ---- 2x2 stride-2 max pool (generator.py:53,60,73; torchvision vgg19 'M') ------------- */
+int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, int ceil_mode,
+                      st_stream_t stream);
+
+/* ---- AdaIN (transformer.py:15-24, 46-59) + alpha blend (trainer.py:434, :702) ---------
+ * out = alpha * ((content - mu_c)/sigma_c * sigma_s + mu_s) + (1 - alpha) * content
+ * sigma = sqrt(var_unbiased + eps), per (n, c) plane; content/style may differ in H*W.
+ * stats (nullable): [n*c][4] = {mu_c, sigma_c, mu_s, sigma_s} saved for backward. */
+int st_adain_fwd(const float* content, const float* style, float* out,
+                 int n, int c, int hw_content, int hw_style,
+                 float eps_content, float eps_style, float alpha,
+                 float* stats, st_stream_t stream);
+
+/* per-plane mean and sqrt(unbiased var + eps)  (AdaIN.calc_mean_std transformer.py:15-24,
+ * AdaINStyleLoss.calc_mean_std losses.py:20-28).  mean, std: [planes] */
+int st_meanstd_fwd(const float* x, float* mean, float* std, int planes, int hw, float eps,
+                   st_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libst_hip.so (C ABI declared in include/st_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a tensor is
+not a contiguous fp32 HIP tensor, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libst_hip.so")
+
+# name -> (restype, argtypes); every symbol include/st_hip.h declares
+SIGNATURES = {
+    "st_version": (c_int, []),
+    "st_last_error": (ctypes.c_char_p, []),
+    "st_conv3x3_packed_elems": (c_size_t, [c_int, c_int]),
+    "st_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p]),
+    "st_conv1x1_3to3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "st_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_adain_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                             c_float, c_void_p, c_void_p]),
+    "st_meanstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+class StHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libst_hip.so and bind every declared symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StHipError(
+            f"{LIB_PATH} not found: build it with `python -m style_transfer_amd.build` "
+            "(there is no CPU fallback for the HIP hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().st_last_error()
+        raise StHipError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev_ptr(t: torch.Tensor, name: str = "tensor") -> int:
+    """Raw device pointer of a contiguous fp32 HIP tensor (loud failure otherwise)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise StHipError(f"{name}: the HIP hot path needs a tensor on the GPU, got device={t.device} "
+                         "(no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
+    if t.dtype != torch.float32:
+        raise StHipError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise StHipError(f"{name}: expected a contiguous tensor")
+    return t.data_ptr()

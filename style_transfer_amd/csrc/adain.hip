@@ -1,0 +1,206 @@
+// AdaIN statistics + remap + alpha blend for gfx950 -- HBM-bound wavefront reductions.
+//
+// Replaces AdaIN.calc_mean_std / adaptive_instance_normalization / forward
+// (transformer.py:15-24, 46-59) and the blend `alpha*t + (1-alpha)*fc` (trainer.py:434,702).
+//
+// One 256-thread block per (n, c) plane.  When both planes fit the register budget
+// (<= 256 threads x V4 float4) the content AND style planes are each read from HBM exactly
+// once with 16-B coalesced loads, the statistics are the exact two-pass form (mean, then
+// centred sum of squares) on registers, and the output is written once: 3 algorithmic
+// passes (read content, read style, write out).  Larger planes stream from global memory
+// (the re-reads of a 16..256 KB plane are served by L2 / Infinity Cache).
+// Reductions are shuffle + fixed-order LDS sums: run-to-run deterministic, no float atomics.
+#include <algorithm>
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct Stats {
+  float mean, m2;
+};
+
+// ---- register-resident path -----------------------------------------------------------
+template <int V4>
+__global__ __launch_bounds__(NT) void adain_reg_kernel(const float* __restrict__ content,
+                                                      const float* __restrict__ style,
+                                                      float* __restrict__ out, int hw_c, int hw_s,
+                                                      float eps_c, float eps_s, float alpha,
+                                                      float* __restrict__ stats) {
+  __shared__ float red[2 * NT / 64];
+  const int tid = threadIdx.x;
+  const size_t plane = blockIdx.x;
+  const float4* c4 = reinterpret_cast<const float4*>(content + plane * hw_c);
+  const float4* s4 = reinterpret_cast<const float4*>(style + plane * hw_s);
+  float4* o4 = reinterpret_cast<float4*>(out + plane * hw_c);
+  const int n4c = hw_c >> 2, n4s = hw_s >> 2;
+
+  float4 cv[V4], sv[V4];
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int idx = tid + i * NT;
+    cv[i] = idx < n4c ? c4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int idx = tid + i * NT;
+    sv[i] = idx < n4s ? s4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float sc = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    sc += (cv[i].x + cv[i].y) + (cv[i].z + cv[i].w);
+    ss += (sv[i].x + sv[i].y) + (sv[i].z + sv[i].w);
+  }
+  // two block sums at once
+  sc = st::wave_sum(sc);
+  ss = st::wave_sum(ss);
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) { red[wave] = sc; red[NT / 64 + wave] = ss; }
+  __syncthreads();
+  float tc = 0.f, ts = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) { tc += red[w]; ts += red[NT / 64 + w]; }
+  const float mean_c = tc / float(hw_c), mean_s = ts / float(hw_s);
+
+  float qc = 0.f, qs = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int idx = tid + i * NT;
+    if (idx < n4c) {
+      const float a = cv[i].x - mean_c, b = cv[i].y - mean_c, c = cv[i].z - mean_c, d = cv[i].w - mean_c;
+      qc += (a * a + b * b) + (c * c + d * d);
+    }
+    if (idx < n4s) {
+      const float a = sv[i].x - mean_s, b = sv[i].y - mean_s, c = sv[i].z - mean_s, d = sv[i].w - mean_s;
+      qs += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  qc = st::wave_sum(qc);
+  qs = st::wave_sum(qs);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[wave] = qc; red[NT / 64 + wave] = qs; }
+  __syncthreads();
+  tc = 0.f; ts = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) { tc += red[w]; ts += red[NT / 64 + w]; }
+  const float std_c = sqrtf(tc / float(hw_c - 1) + eps_c);
+  const float std_s = sqrtf(ts / float(hw_s - 1) + eps_s);
+  if (stats && tid == 0) {
+    float4 sv4 = make_float4(mean_c, std_c, mean_s, std_s);
+    reinterpret_cast<float4*>(stats)[plane] = sv4;
+  }
+  const float inv_c = 1.f / std_c;
+  const float beta = 1.f - alpha;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int idx = tid + i * NT;
+    if (idx < n4c) {
+      float4 v = cv[i], r;
+      r.x = alpha * ((v.x - mean_c) * inv_c * std_s + mean_s) + beta * v.x;
+      r.y = alpha * ((v.y - mean_c) * inv_c * std_s + mean_s) + beta * v.y;
+      r.z = alpha * ((v.z - mean_c) * inv_c * std_s + mean_s) + beta * v.z;
+      r.w = alpha * ((v.w - mean_c) * inv_c * std_s + mean_s) + beta * v.w;
+      o4[idx] = r;
+    }
+  }
+}
+
+// ---- streaming helpers (any hw, any alignment) ------------------------------------------
+__device__ __forceinline__ Stats plane_stats(const float* __restrict__ p, int hw, float* red) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < hw; i += NT) s += p[i];
+  const float mean = st::block_sum<NT>(s, red) / float(hw);
+  float q = 0.f;
+  for (int i = threadIdx.x; i < hw; i += NT) {
+    const float d = p[i] - mean;
+    q += d * d;
+  }
+  Stats r;
+  r.mean = mean;
+  r.m2 = st::block_sum<NT>(q, red);
+  return r;
+}
+
+__global__ __launch_bounds__(NT) void adain_stream_kernel(const float* __restrict__ content,
+                                                         const float* __restrict__ style,
+                                                         float* __restrict__ out, int hw_c,
+                                                         int hw_s, float eps_c, float eps_s,
+                                                         float alpha, float* __restrict__ stats) {
+  __shared__ float red[NT / 64];
+  const size_t plane = blockIdx.x;
+  const float* cp = content + plane * hw_c;
+  const float* sp = style + plane * hw_s;
+  float* op = out + plane * hw_c;
+  const Stats c = plane_stats(cp, hw_c, red);
+  const Stats s = plane_stats(sp, hw_s, red);
+  const float std_c = sqrtf(c.m2 / float(hw_c - 1) + eps_c);
+  const float std_s = sqrtf(s.m2 / float(hw_s - 1) + eps_s);
+  if (stats && threadIdx.x == 0) {
+    stats[plane * 4 + 0] = c.mean; stats[plane * 4 + 1] = std_c;
+    stats[plane * 4 + 2] = s.mean; stats[plane * 4 + 3] = std_s;
+  }
+  const float inv_c = 1.f / std_c, beta = 1.f - alpha;
+  for (int i = threadIdx.x; i < hw_c; i += NT) {
+    const float v = cp[i];
+    op[i] = alpha * ((v - c.mean) * inv_c * std_s + s.mean) + beta * v;
+  }
+}
+
+__global__ __launch_bounds__(NT) void meanstd_kernel(const float* __restrict__ x,
+                                                    float* __restrict__ mean,
+                                                    float* __restrict__ stdv, int hw, float eps) {
+  __shared__ float red[NT / 64];
+  const size_t plane = blockIdx.x;
+  const Stats s = plane_stats(x + plane * hw, hw, red);
+  if (threadIdx.x == 0) {
+    mean[plane] = s.mean;
+    stdv[plane] = sqrtf(s.m2 / float(hw - 1) + eps);
+  }
+}
+
+}  // namespace
+
+extern "C" int st_adain_fwd(const float* content, const float* style, float* out, int n, int c,
+                            int hw_content, int hw_style, float eps_content, float eps_style,
+                            float alpha, float* stats, st_stream_t stream) {
+  ST_REQUIRE(content && style && out, "st_adain_fwd: null pointer");
+  ST_REQUIRE(n > 0 && c > 0 && hw_content > 0 && hw_style > 0,
+             "st_adain_fwd: bad dims n=%d c=%d hw_c=%d hw_s=%d", n, c, hw_content, hw_style);
+  // transformer.py:19 `assert 0 < eps < 1.0`
+  ST_REQUIRE(eps_content > 0.f && eps_content < 1.f && eps_style > 0.f && eps_style < 1.f,
+             "st_adain_fwd: eps must be in (0,1): %g %g", eps_content, eps_style);
+  const long long planes = (long long)n * c;
+  ST_REQUIRE(planes <= 0x7fffffffLL, "st_adain_fwd: too many planes");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)planes), block(NT);
+  const bool vec_ok = (hw_content % 4 == 0) && (hw_style % 4 == 0) &&
+                      (reinterpret_cast<uintptr_t>(content) % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(style) % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
+                      (!stats || reinterpret_cast<uintptr_t>(stats) % 16 == 0);
+  const int need = std::max(hw_content, hw_style);
+  if (vec_ok && need <= NT * 4 * 4) {
+    hipLaunchKernelGGL(adain_reg_kernel<4>, grid, block, 0, s, content, style, out, hw_content,
+                       hw_style, eps_content, eps_style, alpha, stats);
+  } else if (vec_ok && need <= NT * 4 * 16) {
+    hipLaunchKernelGGL(adain_reg_kernel<16>, grid, block, 0, s, content, style, out, hw_content,
+                       hw_style, eps_content, eps_style, alpha, stats);
+  } else {
+    hipLaunchKernelGGL(adain_stream_kernel, grid, block, 0, s, content, style, out, hw_content,
+                       hw_style, eps_content, eps_style, alpha, stats);
+  }
+  return st::check_launch("st_adain_fwd");
+}
+
+extern "C" int st_meanstd_fwd(const float* x, float* mean, float* stdv, int planes, int hw,
+                              float eps, st_stream_t stream) {
+  ST_REQUIRE(x && mean && stdv, "st_meanstd_fwd: null pointer");
+  ST_REQUIRE(planes > 0 && hw > 0, "st_meanstd_fwd: bad dims planes=%d hw=%d", planes, hw);
+  hipLaunchKernelGGL(meanstd_kernel, dim3(planes), dim3(NT), 0, (hipStream_t)stream, x, mean,
+                     stdv, hw, eps);
+  return st::check_launch("st_meanstd_fwd");
+}

@@ -1,0 +1,64 @@
+// Shared host-side helpers for libst_hip.so (error convention of include/st_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "st_hip.h"
+
+namespace st {
+
+char* error_buffer();  // thread-local, 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ST_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return ST_OK;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
+
+}  // namespace st
+
+#define ST_REQUIRE(cond, ...) \
+  do {                        \
+    if (!(cond)) return st::fail(ST_ERR_BAD_ARG, __VA_ARGS__); \
+  } while (0)
+
+// ---- device helpers ---------------------------------------------------------------------
+#ifdef __HIPCC__
+namespace st {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x == NT (multiple of 64); result broadcast to every thread.
+// `red` is an LDS array of at least NT/64 floats.  Fixed order => run-to-run deterministic.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` from a previous use
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t += red[w];
+  return t;
+}
+
+}  // namespace st
+#endif

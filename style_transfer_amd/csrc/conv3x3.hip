@@ -1,0 +1,281 @@
+// 3x3 stride-1 convolution as an fp32 MFMA implicit GEMM for gfx950 (MI355X).
+//
+// Replaces SymmetricPadding2D((1,1,1,1)) -> Conv2d(3x3) -> ReLU of the reference encoder /
+// decoder (generator.py:47-76, 89-117), with the nearest x2 upsample that precedes three
+// decoder convs (generator.py:92,105,112) folded into the load address math, and the
+// zero-padded convs of the torchvision VGG19 loss network (trainer.py:165-199).
+//
+// GEMM view (per image):  D[cout][pixel] = sum_k  Wp[k][cout] * X[k][pixel],  k = (cin, tap).
+//   * M (MFMA rows, register index of D) = output channels, N (MFMA cols, lane) = pixels, so
+//     each accumulator register is one NCHW row segment: 32 consecutive x of one channel
+//     -> every store instruction writes two full 128-B lines.
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (an fmaf chain), 64 cycles / SIMD.
+//   * A block owns BM channels x (TH rows x 32 columns) pixels.  Per K chunk of KC = 8 input
+//     channels it stages the (TH+2) x 34 input halo of each channel ONCE in LDS (edge
+//     replicate / zero pad / upsample resolved here) and re-reads it for all nine taps,
+//     plus the 72 x BM weight slab.  Operand reads are conflict-free ds_read_b32 with
+//     compile-time offsets (32 lanes = 32 consecutive floats).
+//   * The next chunk's global loads are issued before the MFMA phase and written to LDS
+//     after it (register prefetch), several blocks per CU overlap staging with MFMA.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 8;        // input channels per K chunk
+constexpr int TW = 32;       // pixel-tile width == one MFMA N tile
+constexpr int HC = TW + 2;   // halo row length
+constexpr int CPAD = 128;    // packed weights: cout padded to a multiple of this
+constexpr int NTHREADS = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  int n, cin, hs, ws;      // source tensor dims
+  int cout, H, W;          // conv-input (= output) spatial dims, after the optional upsample
+  int cout_pad, nchunks;
+  int up, pad_zero, relu;
+  int tiles_x, tiles_y;
+};
+
+template <int MT, int NT, int WM, int WP>
+struct Cfg {
+  static constexpr int BM = 32 * MT * WM;
+  static constexpr int TH = NT * WP;
+  static constexpr int HR = TH + 2;
+  static constexpr int PLANE = HR * HC;
+  static constexpr int W_ELEMS = 9 * KC * BM;
+  static constexpr int X_ELEMS = KC * PLANE;
+  static constexpr int NP = (PLANE + NTHREADS - 1) / NTHREADS;
+  static constexpr int NW4 = (W_ELEMS / 4 + NTHREADS - 1) / NTHREADS;
+  static constexpr size_t LDS_BYTES = size_t(W_ELEMS + X_ELEMS) * sizeof(float);
+};
+
+template <int MT, int NT, int WM, int WP>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
+  using C = Cfg<MT, NT, WM, WP>;
+  static_assert(WM * WP == 4, "four waves per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;
+  float* Xs = smem + C::W_ELEMS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WP, wp = wave % WP;
+
+  int bt = blockIdx.x;
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int b = bt / p.tiles_y;
+  const int m0 = blockIdx.y * C::BM;
+  const int x0 = tx * TW, y0 = ty * C::TH;
+
+  // ---- per-thread source offsets of the halo positions this thread stages -------------
+  int soff[C::NP];
+#pragma unroll
+  for (int i = 0; i < C::NP; ++i) {
+    const int pidx = tid + i * NTHREADS;
+    int off = -1;
+    if (pidx < C::PLANE) {
+      const int r = pidx / HC, cc = pidx - r * HC;
+      const int gy = y0 + r - 1, gx = x0 + cc - 1;
+      const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      if (inb || !p.pad_zero) {
+        int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+        if (p.up) { cy >>= 1; cx >>= 1; }
+        off = cy * p.ws + cx;
+      }
+    }
+    soff[i] = off;
+  }
+  const size_t plane_src = size_t(p.hs) * p.ws;
+  const float* xb = p.x + size_t(b) * p.cin * plane_src;
+
+  float xr[KC][C::NP];
+  float4 wr[C::NW4];
+
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int cg = chunk * KC + c;
+      const float* src = xb + size_t(cg) * plane_src;
+      const bool cok = cg < p.cin;
+#pragma unroll
+      for (int i = 0; i < C::NP; ++i) xr[c][i] = (cok && soff[i] >= 0) ? src[soff[i]] : 0.f;
+    }
+    const float* wsrc = p.wp + size_t(chunk) * (9 * KC) * p.cout_pad + m0;
+#pragma unroll
+    for (int i = 0; i < C::NW4; ++i) {
+      const int e = tid + i * NTHREADS;
+      if (e < C::W_ELEMS / 4) {
+        const int row = e / (C::BM / 4), c4 = e - row * (C::BM / 4);
+        wr[i] = *reinterpret_cast<const float4*>(wsrc + size_t(row) * p.cout_pad + c4 * 4);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int i = 0; i < C::NP; ++i) {
+        const int pidx = tid + i * NTHREADS;
+        if (pidx < C::PLANE) Xs[c * C::PLANE + pidx] = xr[c][i];
+      }
+#pragma unroll
+    for (int i = 0; i < C::NW4; ++i) {
+      const int e = tid + i * NTHREADS;
+      if (e < C::W_ELEMS / 4) reinterpret_cast<float4*>(Ws)[e] = wr[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const float* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li;
+  const float* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li;
+
+  load_chunk(0);
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    if (chunk) __syncthreads();  // every wave is done reading the previous chunk
+    store_chunk();
+    __syncthreads();
+    if (chunk + 1 < p.nchunks) load_chunk(chunk + 1);  // in flight during the MFMA phase
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int cp = 0; cp < KC / 2; ++cp) {
+        float a[MT], bb[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = aPtr[(tap * KC + 2 * cp) * C::BM + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bb[nt] = bPtr[(2 * cp) * C::PLANE + (nt + dy) * HC + dx];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: bias + ReLU, NCHW store (register r of a tile = one channel row) -----
+  const int xx = x0 + li;
+  if (xx < p.W) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < p.cout) {
+          const float bv = p.bias ? p.bias[co] : 0.f;
+          float* yrow = p.y + (size_t(b) * p.cout + co) * p.H * p.W + xx;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int yy = y0 + wp * NT + nt;
+            if (yy < p.H) {
+              float v = acc[mt][nt][r] + bv;
+              if (p.relu) v = fmaxf(v, 0.f);
+              yrow[size_t(yy) * p.W] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// OIHW -> packed [cin_pad/KC][9][KC][cout_pad] (K-major, output channel contiguous).
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                    int O, int I, int flip, int cout, int cin, int cout_pad,
+                                    long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int o = int(e % cout_pad);
+    long long k = e / cout_pad;
+    const int c = int(k % KC);
+    k /= KC;
+    const int tap = int(k % 9);
+    const int cg = int(k / 9) * KC + c;
+    float v = 0.f;
+    if (o < cout && cg < cin) {
+      v = flip ? w[(size_t(cg) * I + o) * 9 + (8 - tap)] : w[(size_t(o) * I + cg) * 9 + tap];
+    }
+    wp[e] = v;
+  }
+}
+
+template <int MT, int NT, int WM, int WP>
+int launch_conv(ConvParams& p, hipStream_t stream) {
+  using C = Cfg<MT, NT, WM, WP>;
+  p.tiles_x = st::cdiv(p.W, TW);
+  p.tiles_y = st::cdiv(p.H, C::TH);
+  const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
+  ST_REQUIRE(ptiles <= 0x7fffffffLL, "st_conv3x3_fwd: too many pixel tiles (%lld)", ptiles);
+  dim3 grid((unsigned)ptiles, (unsigned)st::cdiv(p.cout, C::BM));
+  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP>), grid, dim3(NTHREADS), C::LDS_BYTES,
+                     stream, p);
+  return st::check_launch("st_conv3x3_fwd");
+}
+
+}  // namespace
+
+extern "C" size_t st_conv3x3_packed_elems(int cout, int cin) {
+  if (cout <= 0 || cin <= 0) return 0;
+  const size_t cin_pad = size_t(st::cdiv(cin, KC)) * KC;
+  const size_t cout_pad = size_t(st::cdiv(cout, CPAD)) * CPAD;
+  return cin_pad * 9 * cout_pad;
+}
+
+extern "C" int st_conv3x3_pack_weights(const float* w_oihw, float* w_packed, int cout, int cin,
+                                       int transpose_flip, st_stream_t stream) {
+  ST_REQUIRE(w_oihw && w_packed, "st_conv3x3_pack_weights: null pointer");
+  ST_REQUIRE(cout > 0 && cin > 0, "st_conv3x3_pack_weights: bad dims cout=%d cin=%d", cout, cin);
+  // (cout, cin) describe the OIHW tensor; the packed filter swaps them when transpose_flip.
+  const int pc_out = transpose_flip ? cin : cout;
+  const int pc_in = transpose_flip ? cout : cin;
+  const int cout_pad = st::cdiv(pc_out, CPAD) * CPAD;
+  const long long total = (long long)st_conv3x3_packed_elems(pc_out, pc_in);
+  const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 4096);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     w_oihw, w_packed, cout, cin, transpose_flip ? 1 : 0, pc_out, pc_in,
+                     cout_pad, total);
+  return st::check_launch("st_conv3x3_pack_weights");
+}
+
+extern "C" int st_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, float* y,
+                              int n, int cin, int hin, int win, int cout, int upsample2x,
+                              int pad_mode, int relu, st_stream_t stream) {
+  ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
+             "st_conv3x3_fwd: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO,
+             "st_conv3x3_fwd: bad pad_mode %d", pad_mode);
+  ST_REQUIRE((long long)hin * win * (upsample2x ? 4 : 1) < (1LL << 31),
+             "st_conv3x3_fwd: plane too large");
+  ConvParams p;
+  p.x = x; p.wp = w_packed; p.bias = bias; p.y = y;
+  p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
+  p.up = upsample2x ? 1 : 0;
+  p.H = hin << p.up; p.W = win << p.up;
+  p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
+  p.nchunks = st::cdiv(cin, KC);
+  p.pad_zero = pad_mode == ST_PAD_ZERO;
+  p.relu = relu ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (cout > 64) return launch_conv<2, 2, 2, 2>(p, s);   // 128 ch x (4 rows x 32)
+  if (cout > 32) return launch_conv<2, 2, 1, 4>(p, s);   //  64 ch x (8 rows x 32)
+  return launch_conv<1, 4, 1, 4>(p, s);                  //  32 ch x (16 rows x 32)
+}

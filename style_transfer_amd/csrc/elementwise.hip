@@ -1,0 +1,80 @@
+// HBM-bound elementwise kernels around the conv stacks:
+//   * 1x1 conv 3->3 on the raw image          (generator.py:46)
+//   * 2x2 stride-2 max pool, ceil / floor     (generator.py:53,60,73; torchvision vgg19 'M')
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void conv1x1_3to3_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ y, long long hw,
+                                                          long long total) {
+  float wr[9], br[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) wr[i] = w[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) br[i] = b ? b[i] : 0.f;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long img = e / hw, pix = e - img * hw;
+    const float* xp = x + img * 3 * hw + pix;
+    float* yp = y + img * 3 * hw + pix;
+    const float x0 = xp[0], x1 = xp[hw], x2 = xp[2 * hw];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+      yp[o * hw] = fmaf(wr[o * 3 + 2], x2, fmaf(wr[o * 3 + 1], x1, fmaf(wr[o * 3], x0, 0.f))) + br[o];
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ y, int h, int w,
+                                                        int ho, int wo, long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ox = int(e % wo);
+    long long t = e / wo;
+    const int oy = int(t % ho);
+    const long long plane = t / ho;
+    const float* xp = x + plane * h * w;
+    const int iy = oy * 2, ix = ox * 2;
+    const bool y1 = iy + 1 < h, x1 = ix + 1 < w;   // partial windows only in ceil mode
+    float m = xp[(size_t)iy * w + ix];
+    if (x1) m = fmaxf(m, xp[(size_t)iy * w + ix + 1]);
+    if (y1) {
+      m = fmaxf(m, xp[(size_t)(iy + 1) * w + ix]);
+      if (x1) m = fmaxf(m, xp[(size_t)(iy + 1) * w + ix + 1]);
+    }
+    y[e] = m;
+  }
+}
+
+inline int grid_for(long long total) {
+  return (int)std::max<long long>(1, std::min<long long>(st::cdivll(total, 256), 256 * 8));
+}
+
+}  // namespace
+
+extern "C" int st_conv1x1_3to3_fwd(const float* x, const float* w, const float* b, float* y,
+                                   int n, int hw, st_stream_t stream) {
+  ST_REQUIRE(x && w && y, "st_conv1x1_3to3_fwd: null pointer");
+  ST_REQUIRE(n > 0 && hw > 0, "st_conv1x1_3to3_fwd: bad dims n=%d hw=%d", n, hw);
+  const long long total = (long long)n * hw;
+  hipLaunchKernelGGL(conv1x1_3to3_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     (hipStream_t)stream, x, w, b, y, (long long)hw, total);
+  return st::check_launch("st_conv1x1_3to3_fwd");
+}
+
+extern "C" int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, int ceil_mode,
+                                 st_stream_t stream) {
+  ST_REQUIRE(x && y, "st_maxpool2x2_fwd: null pointer");
+  ST_REQUIRE(nc > 0 && h > 0 && w > 0, "st_maxpool2x2_fwd: bad dims nc=%d h=%d w=%d", nc, h, w);
+  const int ho = ceil_mode ? (h + 1) / 2 : h / 2, wo = ceil_mode ? (w + 1) / 2 : w / 2;
+  ST_REQUIRE(ho > 0 && wo > 0, "st_maxpool2x2_fwd: empty output for %dx%d floor mode", h, w);
+  const long long total = (long long)nc * ho * wo;
+  hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, h, w, ho, wo, total);
+  return st::check_launch("st_maxpool2x2_fwd");
+}

@@ -1,0 +1,105 @@
+"""Functional host wrappers over the C ABI (include/st_hip.h): shape checks, output
+allocation through torch's caching allocator, raw pointers + current HIP stream.
+
+Forward-only entry points live here; autograd wiring is in ``autograd.py``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+PAD_REPLICATE, PAD_ZERO = 0, 1
+_PAD = {"replicate": PAD_REPLICATE, "symmetric": PAD_REPLICATE, "zero": PAD_ZERO, "zeros": PAD_ZERO}
+
+
+def _pad_code(pad_mode) -> int:
+    if isinstance(pad_mode, int):
+        return pad_mode
+    return _PAD[pad_mode]
+
+
+def pack_conv3x3_weights(w: torch.Tensor, transpose_flip: bool = False) -> torch.Tensor:
+    """OIHW [cout, cin, 3, 3] -> the K-major packed layout st_conv3x3_fwd consumes."""
+    lib = _lib.load()
+    assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3, f"expected OIHW 3x3 weights, got {tuple(w.shape)}"
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    w = w.detach()
+    pc_out, pc_in = (cin, cout) if transpose_flip else (cout, cin)
+    packed = torch.empty(lib.st_conv3x3_packed_elems(pc_out, pc_in), dtype=torch.float32, device=w.device)
+    _lib.check(lib.st_conv3x3_pack_weights(_lib.dev_ptr(w, "w"), _lib.dev_ptr(packed, "packed"), cout, cin,
+                                           1 if transpose_flip else 0, _lib.stream_ptr()),
+               "st_conv3x3_pack_weights")
+    return packed
+
+
+def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+            upsample2x: bool = False, pad_mode="replicate", relu: bool = True) -> torch.Tensor:
+    """act(bias + conv3x3(pad1(up2x(x)))) on NCHW fp32 (generator.py:47-76, 89-117)."""
+    lib = _lib.load()
+    assert x.dim() == 4, "conv3x3 expects NCHW"
+    n, cin, h, w = (int(v) for v in x.shape)
+    need = lib.st_conv3x3_packed_elems(cout, cin)
+    assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} floats, expected {need}"
+    s = 2 if upsample2x else 1
+    y = torch.empty((n, cout, h * s, w * s), dtype=torch.float32, device=x.device)
+    _lib.check(lib.st_conv3x3_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed"),
+                                  _lib.dev_ptr(bias, "bias") if bias is not None else None,
+                                  _lib.dev_ptr(y, "y"), n, cin, h, w, cout, int(upsample2x),
+                                  _pad_code(pad_mode), int(relu), _lib.stream_ptr()), "st_conv3x3_fwd")
+    return y
+
+
+def conv1x1_3to3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.Conv2d(3, 3, (1, 1)) on the raw image (generator.py:46)."""
+    lib = _lib.load()
+    assert x.dim() == 4 and x.shape[1] == 3 and w.numel() == 9
+    n, _, h, wd = (int(v) for v in x.shape)
+    y = torch.empty_like(x)
+    _lib.check(lib.st_conv1x1_3to3_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w.detach(), "w"),
+                                       _lib.dev_ptr(b.detach(), "b") if b is not None else None,
+                                       _lib.dev_ptr(y, "y"), n, h * wd, _lib.stream_ptr()), "st_conv1x1_3to3_fwd")
+    return y
+
+
+def maxpool2x2(x: torch.Tensor, ceil_mode: bool) -> torch.Tensor:
+    """MaxPool2d((2,2),(2,2),(0,0),ceil_mode) (generator.py:53,60,73) / floor (torchvision vgg19)."""
+    lib = _lib.load()
+    n, c, h, w = (int(v) for v in x.shape)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if ceil_mode else (h // 2, w // 2)
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    _lib.check(lib.st_maxpool2x2_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(y, "y"), n * c, h, w, int(ceil_mode),
+                                     _lib.stream_ptr()), "st_maxpool2x2_fwd")
+    return y
+
+
+def adain(content: torch.Tensor, style: torch.Tensor, eps_content: float, eps_style: float,
+          alpha: float = 1.0, save_stats: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """alpha * AdaIN(content, style) + (1 - alpha) * content (transformer.py:46-54, trainer.py:702)."""
+    lib = _lib.load()
+    assert content.dim() == 4 and style.dim() == 4
+    assert content.shape[:2] == style.shape[:2]          # transformer.py:47
+    n, c, hc, wc = (int(v) for v in content.shape)
+    hs, ws = int(style.shape[2]), int(style.shape[3])
+    out = torch.empty_like(content)
+    stats = torch.empty((n * c, 4), dtype=torch.float32, device=content.device) if save_stats else None
+    _lib.check(lib.st_adain_fwd(_lib.dev_ptr(content, "content"), _lib.dev_ptr(style, "style"),
+                                _lib.dev_ptr(out, "out"), n, c, hc * wc, hs * ws, float(eps_content),
+                                float(eps_style), float(alpha),
+                                _lib.dev_ptr(stats, "stats") if stats is not None else None,
+                                _lib.stream_ptr()), "st_adain_fwd")
+    return out, stats
+
+
+def mean_std(x: torch.Tensor, eps: float = 1e-5) -> Tuple[torch.Tensor, torch.Tensor]:
+    """calc_mean_std (transformer.py:15-24 / losses.py:20-28): mean and sqrt(unbiased var + eps), [N,C,1,1]."""
+    lib = _lib.load()
+    assert x.dim() == 4
+    n, c, h, w = (int(v) for v in x.shape)
+    mean = torch.empty((n, c, 1, 1), dtype=torch.float32, device=x.device)
+    std = torch.empty((n, c, 1, 1), dtype=torch.float32, device=x.device)
+    _lib.check(lib.st_meanstd_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(mean, "mean"), _lib.dev_ptr(std, "std"),
+                                  n * c, h * w, float(eps), _lib.stream_ptr()), "st_meanstd_fwd")
+    return mean, std

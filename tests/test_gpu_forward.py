@@ -1,0 +1,99 @@
+"""GPU parity: HIP kernels (through the C ABI) against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3   # BASELINE.json north_star: within 1e-3 relative in fp32
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from style_transfer_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,up,pad,relu", [
+    (1, 8, 32, 8, 8, False, "replicate", True),
+    (2, 3, 64, 37, 45, False, "replicate", True),      # Cin tail, odd sizes
+    (1, 64, 64, 40, 33, False, "replicate", True),
+    (2, 64, 128, 19, 23, False, "replicate", True),
+    (1, 128, 256, 16, 16, False, "zero", True),        # loss-VGG style
+    (1, 256, 256, 9, 11, True, "replicate", True),     # fused nearest x2 upsample
+    (1, 512, 256, 5, 6, False, "replicate", True),
+    (1, 64, 3, 40, 48, False, "replicate", False),     # last decoder conv: no ReLU, Cout=3
+    (1, 20, 130, 7, 70, False, "zero", False),         # ragged channels
+    (1, 16, 40, 1, 1, False, "replicate", True),       # degenerate 1x1 image
+])
+def test_conv3x3(ops, n, cin, cout, h, w, up, pad, relu):
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xin = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    if pad == "replicate":
+        ref = torch.nn.functional.conv2d(R.symmetric_pad(xin), wt, b)
+    else:
+        ref = torch.nn.functional.conv2d(xin, wt, b, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    wp = ops.pack_conv3x3_weights(wt.cuda())
+    y = ops.conv3x3(x.cuda(), wp, b.cuda(), cout, upsample2x=up, pad_mode=pad, relu=relu)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 1e-5
+
+
+def test_conv1x1_and_pool(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 17, 19, generator=g)
+    w = torch.randn(3, 3, 1, 1, generator=g) * 50
+    b = torch.randn(3, generator=g) * 100
+    y = ops.conv1x1_3to3(x.cuda(), w.cuda(), b.cuda())
+    assert rel_err(y, torch.nn.functional.conv2d(x, w, b)) < 1e-6
+    z = torch.randn(2, 5, 17, 19, generator=g)
+    for ceil in (True, False):
+        p = ops.maxpool2x2(z.cuda(), ceil)
+        ref = torch.nn.functional.max_pool2d(z, 2, 2, 0, ceil_mode=ceil)
+        assert p.shape == ref.shape and torch.equal(p.cpu(), ref)
+
+
+@pytest.mark.parametrize("hc,wc,hs,ws", [(7, 9, 5, 4), (64, 64, 64, 64), (64, 64, 32, 48), (128, 128, 128, 128),
+                                          (160, 132, 24, 20)])
+@pytest.mark.parametrize("alpha", [1.0, 0.5, 1.5])
+def test_adain(ops, hc, wc, hs, ws, alpha):
+    g = torch.Generator().manual_seed(hc * 7 + ws)
+    c = torch.randn(2, 6, hc, wc, generator=g) * 2.0 + 0.5
+    s = torch.randn(2, 6, hs, ws, generator=g) * 0.7 - 1.0
+    eps_c, eps_s = 0.02, 1e-5
+    ref = R.blend(R.adain(c, s, style_eps=eps_s, content_eps=eps_c), c, alpha)
+    out, stats = ops.adain(c.cuda(), s.cuda(), eps_c, eps_s, alpha=alpha, save_stats=True)
+    assert rel_err(out, ref) < 1e-5
+    mc, sc = R.calc_mean_std(c, eps_c)
+    ms, ss = R.calc_mean_std(s, eps_s)
+    st = stats.cpu().view(2, 6, 4)
+    np.testing.assert_allclose(st[..., 0], mc.view(2, 6), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[..., 1], sc.view(2, 6), rtol=1e-5)
+    np.testing.assert_allclose(st[..., 2], ms.view(2, 6), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[..., 3], ss.view(2, 6), rtol=1e-5)
+
+
+def test_adain_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "adain.npz"))
+    c, s = torch.from_numpy(g["content"]), torch.from_numpy(g["style"])
+    # eps_limit 0.1: content_eps -> sqrt(4e-4)=0.02, style_eps -> sqrt(2.5e-3)=0.05 (reference output)
+    out, _ = ops.adain(c.cuda(), s.cuda(), float(g["eps_0.1"][1]), float(g["eps_0.1"][0]))
+    assert rel_err(out, torch.from_numpy(g["out_0.1"])) < 1e-5
+    mean, std = ops.mean_std(c.cuda(), 1e-5)
+    assert rel_err(mean, torch.from_numpy(g["mean"])) < 1e-5
+    assert rel_err(std, torch.from_numpy(g["std"])) < 1e-5
