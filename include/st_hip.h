@@ -74,6 +74,13 @@ int st_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, flo
                    int n, int cin, int hin, int win, int cout,
                    int upsample2x, int pad_mode, int relu, st_stream_t stream);
 
+/* ---- SymmetricPadding2D.forward, any padding (generator.py:14-39) ----------------------
+ * numpy-"symmetric" reflection about the half-pixel points -0.5 and n-0.5 (edge pixel
+ * repeated).  x: [nc][h][w] -> y: [nc][h+top+bottom][w+left+right].  The fused 3x3 conv
+ * never materialises this tensor; the entry point exists for the stand-alone module. */
+int st_sympad_fwd(const float* x, float* y, int nc, int h, int w, int left, int right, int top,
+                  int bottom, st_stream_t stream);
+
 /* ---- 1x1 convolution 3->3 on the raw image (generator.py:46) ------------------------- */
 int st_conv1x1_3to3_fwd(const float* x, const float* w /*[3][3]*/, const float* b /*[3]*/,
                         float* y, int n, int hw, st_stream_t stream);

@@ -78,3 +78,40 @@ extern "C" int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w,
                      x, y, h, w, ho, wo, total);
   return st::check_launch("st_maxpool2x2_fwd");
 }
+
+// ---- SymmetricPadding2D, any (left, right, top, bottom) (generator.py:14-39) -------------
+namespace {
+
+// numpy "symmetric" reflection about -0.5 and n-0.5: period 2n triangular wave.
+__device__ __forceinline__ int sym_index(int i, int n) {
+  int m = i % (2 * n);
+  if (m < 0) m += 2 * n;
+  return m >= n ? 2 * n - 1 - m : m;
+}
+
+__global__ __launch_bounds__(256) void sympad_kernel(const float* __restrict__ x,
+                                                    float* __restrict__ y, int h, int w, int left,
+                                                    int top, int ho, int wo, long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ox = int(e % wo);
+    long long t = e / wo;
+    const int oy = int(t % ho);
+    const long long plane = t / ho;
+    y[e] = x[plane * h * w + (size_t)sym_index(oy - top, h) * w + sym_index(ox - left, w)];
+  }
+}
+
+}  // namespace
+
+extern "C" int st_sympad_fwd(const float* x, float* y, int nc, int h, int w, int left, int right,
+                             int top, int bottom, st_stream_t stream) {
+  ST_REQUIRE(x && y, "st_sympad_fwd: null pointer");
+  ST_REQUIRE(nc > 0 && h > 0 && w > 0, "st_sympad_fwd: bad dims nc=%d h=%d w=%d", nc, h, w);
+  ST_REQUIRE(left >= 0 && right >= 0 && top >= 0 && bottom >= 0, "st_sympad_fwd: negative padding");
+  const int ho = h + top + bottom, wo = w + left + right;
+  const long long total = (long long)nc * ho * wo;
+  hipLaunchKernelGGL(sympad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     h, w, left, top, ho, wo, total);
+  return st::check_launch("st_sympad_fwd");
+}

@@ -1,0 +1,151 @@
+"""Encoder / Decoder / SymmetricPadding2D with the reference's names, constructor
+signatures, forward signatures and state_dict keys (src/models/generator.py:14-130),
+running on hand-written HIP kernels (libst_hip.so) instead of stock ATen dispatch.
+
+The ``nn.Sequential`` containers keep the reference's module positions so
+``state_dict()`` keys (``encode.{0,2,...,29}.*`` / ``decoder.{1,...,28}.*``) and
+``.pth`` files are interchangeable, but ``forward`` never runs the Sequential: each
+[SymmetricPadding2D -> Conv2d(3x3) -> ReLU] triple (and a preceding nearest x2
+upsample) is ONE fused MFMA implicit-GEMM launch.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .autograd import conv3x3_apply, maxpool2x2_apply, conv1x1_apply, sympad_apply
+
+ENCODER_WEIGHTS = r'./src/models/checkpoints/WCT_encoder_decoder/vgg_normalised_conv4_1.pth'   # generator.py:78
+DECODER_WEIGHTS = r"./src/models/checkpoints/WCT_encoder_decoder/feature_invertor_conv4_1.pth"  # generator.py:121
+
+
+class SymmetricPadding2D(nn.Module):
+    """generator.py:14-39.  padding = (left, right, top, bottom)."""
+
+    def __init__(self, padding: Tuple[int, int, int, int] = (1, 1, 1, 1)):
+        super().__init__()
+        self.padding = padding
+
+    def forward(self, im: torch.Tensor):
+        return sympad_apply(im, self.padding)
+
+
+class _PackedWeightCache:
+    """Packed (K-major) copies of OIHW conv weights; rebuilt when the parameter changes."""
+
+    def __init__(self):
+        self._c: Dict[Tuple[int, bool], Tuple[int, int, torch.Tensor]] = {}
+
+    def get(self, key, w: torch.Tensor, transpose_flip: bool = False) -> torch.Tensor:
+        ent = self._c.get((key, transpose_flip))
+        if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
+            return ent[2]
+        packed = ops.pack_conv3x3_weights(w, transpose_flip)
+        self._c[(key, transpose_flip)] = (w._version, w.data_ptr(), packed)
+        return packed
+
+    def clear(self):
+        self._c.clear()
+
+
+def _load_state(path_or_sd: Union[str, dict]) -> dict:
+    if isinstance(path_or_sd, dict):
+        return path_or_sd
+    return torch.load(path_or_sd, map_location="cpu", weights_only=True)
+
+
+class Encoder(nn.Module):
+    """VGG19-normalised encoder up to relu4_1 (generator.py:42-82).
+
+    ``Encoder()`` behaves like the reference: it loads the cwd-relative
+    ``vgg_normalised_conv4_1.pth`` and raises FileNotFoundError when it is missing.
+    ``weights`` may instead be another path, a state dict with the bare Sequential keys
+    (``"0.weight"`` ...), or ``False`` to keep the random initialisation.
+    The encoder is frozen (no optimizer in the reference ever reads its gradients,
+    trainer.py:286-297), so its parameters do not require grad.
+    """
+
+    POOL_AFTER = (5, 12, 25)   # ceil-mode pools at Sequential indices 7, 14, 27
+
+    def __init__(self, weights: Union[str, dict, bool, None] = None):
+        super().__init__()
+        self.encode = nn.Sequential(
+            nn.Conv2d(3, 3, (1, 1)),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(3, 64, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(64, 64, (3, 3)), nn.ReLU(),
+            nn.MaxPool2d((2, 2), (2, 2), (0, 0), ceil_mode=True),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(64, 128, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(128, 128, (3, 3)), nn.ReLU(),
+            nn.MaxPool2d((2, 2), (2, 2), (0, 0), ceil_mode=True),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(128, 256, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 256, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 256, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 256, (3, 3)), nn.ReLU(),
+            nn.MaxPool2d((2, 2), (2, 2), (0, 0), ceil_mode=True),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 512, (3, 3)), nn.ReLU(),
+        )
+        if weights is not False:
+            self.encode.load_state_dict(_load_state(ENCODER_WEIGHTS if weights is None else weights))
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self._packed = _PackedWeightCache()
+
+    CONV3 = (2, 5, 9, 12, 16, 19, 22, 25, 29)
+
+    def forward(self, x):
+        seq = self.encode
+        x = conv1x1_apply(x, seq[0].weight, seq[0].bias)
+        for idx in self.CONV3:
+            conv = seq[idx]
+            x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=False,
+                              pad_mode=ops.PAD_REPLICATE, relu=True)
+            if idx in self.POOL_AFTER:
+                x = maxpool2x2_apply(x, ceil_mode=True)
+        return x
+
+
+class Decoder(nn.Module):
+    """Mirrored decoder (generator.py:85-130): keys ``decoder.{1,5,8,11,14,18,21,25,28}``."""
+
+    CONV3 = (1, 5, 8, 11, 14, 18, 21, 25, 28)
+    UP_AFTER = (1, 14, 21)
+
+    def __init__(self, use_pretrained_WCT: bool = False, do_train: bool = False,
+                 weights: Union[str, dict, None] = None):
+        super().__init__()
+        self.decoder = nn.Sequential(
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(512, 256, (3, 3)), nn.ReLU(),
+            nn.UpsamplingNearest2d(scale_factor=2),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 256, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 256, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 256, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(256, 128, (3, 3)), nn.ReLU(),
+            nn.UpsamplingNearest2d(scale_factor=2),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(128, 128, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(128, 64, (3, 3)), nn.ReLU(),
+            nn.UpsamplingNearest2d(scale_factor=2),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(64, 64, (3, 3)), nn.ReLU(),
+            SymmetricPadding2D((1, 1, 1, 1)), nn.Conv2d(64, 3, (3, 3)),
+        )
+        if use_pretrained_WCT:
+            print("\n Using WCT pretrained image recover...")
+            self.decoder.load_state_dict(_load_state(DECODER_WEIGHTS if weights is None else weights))
+        if do_train:
+            print("\n Enabling Decoder training...")
+            self.decoder.train()
+        else:
+            self.decoder.eval()
+        self._packed = _PackedWeightCache()
+
+    def forward(self, x):
+        seq = self.decoder
+        up = False
+        for idx in self.CONV3:
+            conv = seq[idx]
+            x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=up,
+                              pad_mode=ops.PAD_REPLICATE, relu=(idx != 28))
+            up = idx in self.UP_AFTER     # the next conv reads this output through a x2 nearest upsample
+        return x

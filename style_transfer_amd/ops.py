@@ -12,6 +12,45 @@ import torch
 from . import _lib
 
 PAD_REPLICATE, PAD_ZERO = 0, 1
+
+
+class _KernelTimer:
+    """Optional per-launch HIP-event timing (used by bench.py for the roofline object).
+    Events are recorded on torch's current stream, the stream every kernel is launched on."""
+
+    def __init__(self):
+        self.enabled = False
+        self._pending = []
+
+    def start(self):
+        self.enabled = True
+        self._pending = []
+
+    def record(self, kernel: str, flops: float, nbytes: float):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        self._pending.append((kernel, flops, nbytes, e0, e1))
+        e0.record()
+        return e1
+
+    def stop(self):
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = [{"kernel": k, "flops": f, "bytes": b, "ms": e0.elapsed_time(e1)} for k, f, b, e0, e1 in self._pending]
+        self._pending = []
+        return out
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
+def conv_kernel_name(cout: int) -> str:
+    """Template instantiation st_conv3x3_fwd dispatches to (csrc/conv3x3.hip)."""
+    if cout > 64:
+        return "conv3x3_f32_kernel<2,2,2,2>"
+    if cout > 32:
+        return "conv3x3_f32_kernel<2,2,1,4>"
+    return "conv3x3_f32_kernel<1,4,1,4>"
 _PAD = {"replicate": PAD_REPLICATE, "symmetric": PAD_REPLICATE, "zero": PAD_ZERO, "zeros": PAD_ZERO}
 
 
@@ -45,10 +84,29 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} floats, expected {need}"
     s = 2 if upsample2x else 1
     y = torch.empty((n, cout, h * s, w * s), dtype=torch.float32, device=x.device)
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cout), 2.0 * n * h * s * w * s * cin * cout * 9,
+                                 4.0 * (x.numel() + y.numel()))
     _lib.check(lib.st_conv3x3_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed"),
                                   _lib.dev_ptr(bias, "bias") if bias is not None else None,
                                   _lib.dev_ptr(y, "y"), n, cin, h, w, cout, int(upsample2x),
                                   _pad_code(pad_mode), int(relu), _lib.stream_ptr()), "st_conv3x3_fwd")
+    if ev is not None:
+        ev.record()
+    return y
+
+
+def sympad(x: torch.Tensor, padding=(1, 1, 1, 1)) -> torch.Tensor:
+    """SymmetricPadding2D.forward (generator.py:19-39); padding = (left, right, top, bottom)."""
+    lib = _lib.load()
+    left, right, top, bottom = (int(v) for v in padding)
+    h, w = int(x.shape[-2]), int(x.shape[-1])
+    nc = x.numel() // (h * w)
+    y = torch.empty(tuple(x.shape[:-2]) + (h + top + bottom, w + left + right), dtype=torch.float32,
+                    device=x.device)
+    _lib.check(lib.st_sympad_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(y, "y"), nc, h, w, left, right, top, bottom,
+                                 _lib.stream_ptr()), "st_sympad_fwd")
     return y
 
 
