@@ -30,6 +30,7 @@ constexpr int CPAD = 128;    // packed weights: cout padded to a multiple of thi
 constexpr int NTHREADS = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
   const float* x;
@@ -78,62 +79,69 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
   const int x0 = tx * TW, y0 = ty * C::TH;
 
   // ---- per-thread source offsets of the halo positions this thread stages -------------
+  // Every load below is unconditional (clamped, always in-bounds address) and the zero
+  // cases (zero padding, channel tail) are selects, so the prefetch registers stay in
+  // VGPRs and the loads issue back to back.
   int soff[C::NP];
+  unsigned smask[C::NP];   // all-ones: keep the loaded value; 0: zero padding
 #pragma unroll
   for (int i = 0; i < C::NP; ++i) {
     const int pidx = tid + i * NTHREADS;
-    int off = -1;
-    if (pidx < C::PLANE) {
-      const int r = pidx / HC, cc = pidx - r * HC;
-      const int gy = y0 + r - 1, gx = x0 + cc - 1;
-      const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      if (inb || !p.pad_zero) {
-        int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-        if (p.up) { cy >>= 1; cx >>= 1; }
-        off = cy * p.ws + cx;
-      }
-    }
-    soff[i] = off;
+    const int r = pidx / HC, cc = pidx - r * HC;
+    const int gy = y0 + r - 1, gx = x0 + cc - 1;
+    const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+    if (p.up) { cy >>= 1; cx >>= 1; }
+    soff[i] = cy * p.ws + cx;
+    smask[i] = (inb || !p.pad_zero) ? 0xffffffffu : 0u;
   }
   const size_t plane_src = size_t(p.hs) * p.ws;
   const float* xb = p.x + size_t(b) * p.cin * plane_src;
 
   float xr[KC][C::NP];
-  float4 wr[C::NW4];
+  f32x4 wr[C::NW4];
+  // weight slab addressing: float4 index e -> (row, c4); clamp e so the tail threads of the
+  // last pass re-load a valid element (their LDS write is skipped)
+  int woff[C::NW4];
+#pragma unroll
+  for (int i = 0; i < C::NW4; ++i) {
+    const int e = min(tid + i * NTHREADS, C::W_ELEMS / 4 - 1);
+    const int row = e / (C::BM / 4), c4 = e - row * (C::BM / 4);
+    woff[i] = row * p.cout_pad + c4 * 4;
+  }
 
-  auto load_chunk = [&](int chunk) {
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const int cg = chunk * KC + c;
-      const float* src = xb + size_t(cg) * plane_src;
-      const bool cok = cg < p.cin;
-#pragma unroll
-      for (int i = 0; i < C::NP; ++i) xr[c][i] = (cok && soff[i] >= 0) ? src[soff[i]] : 0.f;
-    }
-    const float* wsrc = p.wp + size_t(chunk) * (9 * KC) * p.cout_pad + m0;
-#pragma unroll
-    for (int i = 0; i < C::NW4; ++i) {
-      const int e = tid + i * NTHREADS;
-      if (e < C::W_ELEMS / 4) {
-        const int row = e / (C::BM / 4), c4 = e - row * (C::BM / 4);
-        wr[i] = *reinterpret_cast<const float4*>(wsrc + size_t(row) * p.cout_pad + c4 * 4);
-      }
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int i = 0; i < C::NP; ++i) {
-        const int pidx = tid + i * NTHREADS;
-        if (pidx < C::PLANE) Xs[c * C::PLANE + pidx] = xr[c][i];
-      }
-#pragma unroll
-    for (int i = 0; i < C::NW4; ++i) {
-      const int e = tid + i * NTHREADS;
-      if (e < C::W_ELEMS / 4) reinterpret_cast<float4*>(Ws)[e] = wr[i];
-    }
-  };
+#define ST_LOAD_CHUNK(chunk_)                                                          \
+  {                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                   \
+      const int cg = (chunk_) * KC + c;                                                \
+      const float* src = xb + size_t(min(cg, p.cin - 1)) * plane_src;                  \
+      _Pragma("unroll") for (int i = 0; i < C::NP; ++i) xr[c][i] = src[soff[i]];       \
+    }                                                                                  \
+    const float* wsrc = p.wp + size_t(chunk_) * (9 * KC) * p.cout_pad + m0;            \
+    _Pragma("unroll") for (int i = 0; i < C::NW4; ++i)                                 \
+        wr[i] = *reinterpret_cast<const f32x4*>(wsrc + woff[i]);                      \
+  }
+
+  // Zero padding / channel tail are applied at the LDS store, as bit masks: a select on a
+  // uniform condition at the load makes hipcc branch around it with a vmcnt(0) per element,
+  // and a mask at the load is waited for before the MFMA phase instead of after it.
+#define ST_STORE_CHUNK(chunk_)                                                         \
+  {                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                   \
+      const unsigned cmask = ((chunk_) * KC + c) < p.cin ? 0xffffffffu : 0u;           \
+      _Pragma("unroll") for (int i = 0; i < C::NP; ++i) {                              \
+        const int pidx = tid + i * NTHREADS;                                           \
+        if (C::PLANE % NTHREADS == 0 || pidx < C::PLANE)                               \
+          Xs[c * C::PLANE + pidx] =                                                    \
+              __uint_as_float(__float_as_uint(xr[c][i]) & (smask[i] & cmask));         \
+      }                                                                                \
+    }                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < C::NW4; ++i) {                               \
+      const int e = tid + i * NTHREADS;                                                \
+      if ((C::W_ELEMS / 4) % NTHREADS == 0 || e < C::W_ELEMS / 4)                      \
+        reinterpret_cast<f32x4*>(Ws)[e] = wr[i];                                      \
+    }                                                                                  \
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -146,12 +154,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
   const float* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li;
   const float* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li;
 
-  load_chunk(0);
+  ST_LOAD_CHUNK(0);
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
     if (chunk) __syncthreads();  // every wave is done reading the previous chunk
-    store_chunk();
+    ST_STORE_CHUNK(chunk);
     __syncthreads();
-    if (chunk + 1 < p.nchunks) load_chunk(chunk + 1);  // in flight during the MFMA phase
+    if (chunk + 1 < p.nchunks) ST_LOAD_CHUNK(chunk + 1);  // in flight during the MFMA phase
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
@@ -196,6 +204,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
     }
   }
 }
+
+#undef ST_LOAD_CHUNK
+#undef ST_STORE_CHUNK
 
 // OIHW -> packed [cin_pad/KC][9][KC][cout_pad] (K-major, output channel contiguous).
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the fp32 MFMA conv3x3 kernel on the encoder/decoder shapes
+(BASELINE configs[1]: batch 16 at 512x512).  HIP events on the launch stream.
+
+    python tools/bench_conv_layers.py [--batch 16] [--side 512] [--iters 5]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from style_transfer_amd import ops
+
+# (name, cin, cout, side_divisor_of_input, upsample)
+LAYERS = [
+    ("enc conv1_1", 3, 64, 1, False), ("enc conv1_2", 64, 64, 1, False),
+    ("enc conv2_1", 64, 128, 2, False), ("enc conv2_2", 128, 128, 2, False),
+    ("enc conv3_1", 128, 256, 4, False), ("enc conv3_x", 256, 256, 4, False),
+    ("enc conv4_1", 256, 512, 8, False),
+    ("dec 1", 512, 256, 8, False), ("dec 5 up", 256, 256, 8, True), ("dec 8/11", 256, 256, 4, False),
+    ("dec 14", 256, 128, 4, False), ("dec 18 up", 128, 128, 4, True), ("dec 21", 128, 64, 2, False),
+    ("dec 25 up", 64, 64, 2, True), ("dec 28", 64, 3, 1, False),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--side", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    tot_t = tot_f = 0.0
+    for name, cin, cout, div, up in LAYERS:
+        h = args.side // div
+        x = torch.randn(args.batch, cin, h, h, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+        b = torch.randn(cout, device=dev)
+        wp = ops.pack_conv3x3_weights(w)
+        ops.conv3x3(x, wp, b, cout, upsample2x=up)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ops.conv3x3(x, wp, b, cout, upsample2x=up)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        ho = h * (2 if up else 1)
+        fl = 2.0 * args.batch * ho * ho * cin * cout * 9
+        tot_t += ms
+        tot_f += fl
+        print(f"{name:14s} cin={cin:3d} cout={cout:3d} out={ho:4d}^2  {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TF/s", flush=True)
+    print(f"sum {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.2f} TF/s over the listed layers")
+
+
+if __name__ == "__main__":
+    main()
