@@ -74,6 +74,29 @@ int st_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, flo
                    int n, int cin, int hin, int win, int cout,
                    int upsample2x, int pad_mode, int relu, st_stream_t stream);
 
+/* Data gradient of the layer above (decoder backward, trainer.py:472; loss-VGG backward).
+ *   dy:      [n][cout][h][w]   gradient w.r.t. the layer output (h, w = OUTPUT dims)
+ *   y_gate:  nullable; the layer's post-ReLU output: dy is taken as 0 where y_gate <= 0
+ *   w_packed_t: st_conv3x3_pack_weights(..., transpose_flip = 1)
+ *   dx:      [n][cin][h/s][w/s], s = 2 if the layer had the fused upsample, else 1
+ * ST_PAD_ZERO: one MFMA launch writes dx.  ST_PAD_REPLICATE: the gradient is evaluated on the
+ * padded (h+2) x (w+2) domain into `workspace` (st_conv3x3_dgrad_workspace_bytes) and folded
+ * back onto the replicated edges (and 2x2-summed for the upsample) by a second launch. */
+size_t st_conv3x3_dgrad_workspace_bytes(int n, int cin, int h, int w, int pad_mode);
+int st_conv3x3_dgrad(const float* dy, const float* y_gate, const float* w_packed_t, float* dx,
+                     float* workspace, int n, int cout, int h, int w, int cin, int upsample2x,
+                     int pad_mode, st_stream_t stream);
+
+/* Weight and bias gradient (decoder training, trainer.py:286-291, 471-473).
+ *   x: [n][cin][hin][win] layer input; dy / y_gate: [n][cout][H][W], H = (upsample2x?2:1)*hin
+ *   dw: [cout][cin][3][3] (OIHW, overwritten); dbias: [cout] or NULL
+ * Split-K partial slabs go to `workspace` (st_conv3x3_wgrad_workspace_bytes) and are summed in
+ * a fixed order: deterministic, no float atomics.  dy and y_gate must be 16-byte aligned. */
+size_t st_conv3x3_wgrad_workspace_bytes(int n, int cout, int cin, int h, int w);
+int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_gate, float* dw,
+                     float* dbias, float* workspace, int n, int cin, int hin, int win, int cout,
+                     int upsample2x, int pad_mode, st_stream_t stream);
+
 /* ---- SymmetricPadding2D.forward, any padding (generator.py:14-39) ----------------------
  * numpy-"symmetric" reflection about the half-pixel points -0.5 and n-0.5 (edge pixel
  * repeated).  x: [nc][h][w] -> y: [nc][h+top+bottom][w+left+right].  The fused 3x3 conv
@@ -88,6 +111,11 @@ int st_conv1x1_3to3_fwd(const float* x, const float* w /*[3][3]*/, const float* 
 /* ---- 2x2 stride-2 max pool (generator.py:53,60,73; torchvision vgg19 'M') ------------- */
 int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, int ceil_mode,
                       st_stream_t stream);
+
+/* backward: x is the pool INPUT [nc][h][w], dy [nc][ho][wo]; dx [nc][h][w] fully overwritten.
+ * Ties go to the first maximum in scan order, as torch.max_pool2d does. */
+int st_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,
+                      int ceil_mode, st_stream_t stream);
 
 /* ---- AdaIN (transformer.py:15-24, 46-59) + alpha blend (trainer.py:434, :702) ---------
  * out = alpha * ((content - mu_c)/sigma_c * sigma_s + mu_s) + (1 - alpha) * content

@@ -34,11 +34,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
   const float* x;
+  const float* gate;       // GATE kernels: same shape as x; x is read as 0 where gate <= 0
   const float* wp;
   const float* bias;
   float* y;
   int n, cin, hs, ws;      // source tensor dims
-  int cout, H, W;          // conv-input (= output) spatial dims, after the optional upsample
+  int cout, H, W;          // conv-input spatial dims, after the optional upsample
+  int Ho, Wo;              // output dims: (H, W) forward; (H+2, W+2) for the padded data gradient
+  int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
   int up, pad_zero, relu;
   int tiles_x, tiles_y;
@@ -57,7 +60,7 @@ struct Cfg {
   static constexpr size_t LDS_BYTES = size_t(W_ELEMS + X_ELEMS) * sizeof(float);
 };
 
-template <int MT, int NT, int WM, int WP>
+template <int MT, int NT, int WM, int WP, bool GATE>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
   using C = Cfg<MT, NT, WM, WP>;
   static_assert(WM * WP == 4, "four waves per block");
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
   for (int i = 0; i < C::NP; ++i) {
     const int pidx = tid + i * NTHREADS;
     const int r = pidx / HC, cc = pidx - r * HC;
-    const int gy = y0 + r - 1, gx = x0 + cc - 1;
+    const int gy = y0 + r - 1 - p.shift, gx = x0 + cc - 1 - p.shift;
     const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
     if (p.up) { cy >>= 1; cx >>= 1; }
@@ -97,8 +100,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
   }
   const size_t plane_src = size_t(p.hs) * p.ws;
   const float* xb = p.x + size_t(b) * p.cin * plane_src;
+  const float* gb = GATE ? p.gate + size_t(b) * p.cin * plane_src : nullptr;
 
   float xr[KC][C::NP];
+  float gr[GATE ? KC : 1][C::NP];   // ReLU gate prefetch (data-gradient kernels)
   f32x4 wr[C::NW4];
   // weight slab addressing: float4 index e -> (row, c4); clamp e so the tail threads of the
   // last pass re-load a valid element (their LDS write is skipped)
@@ -116,6 +121,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
       const int cg = (chunk_) * KC + c;                                                \
       const float* src = xb + size_t(min(cg, p.cin - 1)) * plane_src;                  \
       _Pragma("unroll") for (int i = 0; i < C::NP; ++i) xr[c][i] = src[soff[i]];       \
+      if (GATE) {                                                                      \
+        const float* gsrc = gb + size_t(min(cg, p.cin - 1)) * plane_src;               \
+        _Pragma("unroll") for (int i = 0; i < C::NP; ++i) gr[c][i] = gsrc[soff[i]];    \
+      }                                                                                \
     }                                                                                  \
     const float* wsrc = p.wp + size_t(chunk_) * (9 * KC) * p.cout_pad + m0;            \
     _Pragma("unroll") for (int i = 0; i < C::NW4; ++i)                                 \
@@ -131,9 +140,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
       const unsigned cmask = ((chunk_) * KC + c) < p.cin ? 0xffffffffu : 0u;           \
       _Pragma("unroll") for (int i = 0; i < C::NP; ++i) {                              \
         const int pidx = tid + i * NTHREADS;                                           \
+        unsigned m = smask[i] & cmask;                                                 \
+        if (GATE) m &= gr[c][i] > 0.f ? 0xffffffffu : 0u;                              \
         if (C::PLANE % NTHREADS == 0 || pidx < C::PLANE)                               \
-          Xs[c * C::PLANE + pidx] =                                                    \
-              __uint_as_float(__float_as_uint(xr[c][i]) & (smask[i] & cmask));         \
+          Xs[c * C::PLANE + pidx] = __uint_as_float(__float_as_uint(xr[c][i]) & m);    \
       }                                                                                \
     }                                                                                  \
     _Pragma("unroll") for (int i = 0; i < C::NW4; ++i) {                               \
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
 
   // ---- epilogue: bias + ReLU, NCHW store (register r of a tile = one channel row) -----
   const int xx = x0 + li;
-  if (xx < p.W) {
+  if (xx < p.Wo) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -189,14 +199,14 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
         const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (co < p.cout) {
           const float bv = p.bias ? p.bias[co] : 0.f;
-          float* yrow = p.y + (size_t(b) * p.cout + co) * p.H * p.W + xx;
+          float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.Wo + xx;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int yy = y0 + wp * NT + nt;
-            if (yy < p.H) {
+            if (yy < p.Ho) {
               float v = acc[mt][nt][r] + bv;
               if (p.relu) v = fmaxf(v, 0.f);
-              yrow[size_t(yy) * p.W] = v;
+              yrow[size_t(yy) * p.Wo] = v;
             }
           }
         }
@@ -228,17 +238,52 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-template <int MT, int NT, int WM, int WP>
+// Adjoint of the edge-replicate pad (+ optional nearest x2 upsample) on the padded data
+// gradient dxp [planes][H+2][W+2]:  dx[i][j] = sum of dxp over every padded position that the
+// forward pass read from source pixel (i, j).
+__global__ __launch_bounds__(256) void dgrad_fold_kernel(const float* __restrict__ dxp,
+                                                        float* __restrict__ dx, int H, int W,
+                                                        int up, int hs, int ws, long long total) {
+  const int Wp = W + 2;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int j = int(e % ws);
+    long long t = e / ws;
+    const int i = int(t % hs);
+    const long long plane = t / hs;
+    const float* src = dxp + plane * (long long)(H + 2) * Wp;
+    // conv-input rows covered by source row i, then widened over the replicated border
+    int u0 = up ? 2 * i : i, u1 = up ? 2 * i + 1 : i;
+    int v0 = up ? 2 * j : j, v1 = up ? 2 * j + 1 : j;
+    if (u0 == 0) u0 = -1;
+    if (u1 == H - 1) u1 = H;
+    if (v0 == 0) v0 = -1;
+    if (v1 == W - 1) v1 = W;
+    float s = 0.f;
+    for (int u = u0; u <= u1; ++u)
+      for (int v = v0; v <= v1; ++v) s += src[(size_t)(u + 1) * Wp + (v + 1)];
+    dx[e] = s;
+  }
+}
+
+template <int MT, int NT, int WM, int WP, bool GATE>
 int launch_conv(ConvParams& p, hipStream_t stream) {
   using C = Cfg<MT, NT, WM, WP>;
-  p.tiles_x = st::cdiv(p.W, TW);
-  p.tiles_y = st::cdiv(p.H, C::TH);
+  p.tiles_x = st::cdiv(p.Wo, TW);
+  p.tiles_y = st::cdiv(p.Ho, C::TH);
   const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
-  ST_REQUIRE(ptiles <= 0x7fffffffLL, "st_conv3x3_fwd: too many pixel tiles (%lld)", ptiles);
+  ST_REQUIRE(ptiles <= 0x7fffffffLL, "st_conv3x3: too many pixel tiles (%lld)", ptiles);
   dim3 grid((unsigned)ptiles, (unsigned)st::cdiv(p.cout, C::BM));
-  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP>), grid, dim3(NTHREADS), C::LDS_BYTES,
-                     stream, p);
-  return st::check_launch("st_conv3x3_fwd");
+  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP, GATE>), grid, dim3(NTHREADS),
+                     C::LDS_BYTES, stream, p);
+  return st::check_launch("st_conv3x3");
+}
+
+template <bool GATE>
+int dispatch_conv(ConvParams& p, hipStream_t s) {
+  if (p.cout > 64) return launch_conv<2, 2, 2, 2, GATE>(p, s);   // 128 ch x (4 rows x 32)
+  if (p.cout > 32) return launch_conv<2, 2, 1, 4, GATE>(p, s);   //  64 ch x (8 rows x 32)
+  return launch_conv<1, 4, 1, 4, GATE>(p, s);                    //  32 ch x (16 rows x 32)
 }
 
 }  // namespace
@@ -277,16 +322,59 @@ extern "C" int st_conv3x3_fwd(const float* x, const float* w_packed, const float
   ST_REQUIRE((long long)hin * win * (upsample2x ? 4 : 1) < (1LL << 31),
              "st_conv3x3_fwd: plane too large");
   ConvParams p;
-  p.x = x; p.wp = w_packed; p.bias = bias; p.y = y;
+  p.x = x; p.gate = nullptr; p.wp = w_packed; p.bias = bias; p.y = y;
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
   p.up = upsample2x ? 1 : 0;
   p.H = hin << p.up; p.W = win << p.up;
+  p.Ho = p.H; p.Wo = p.W; p.shift = 0;
   p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
   p.nchunks = st::cdiv(cin, KC);
   p.pad_zero = pad_mode == ST_PAD_ZERO;
   p.relu = relu ? 1 : 0;
+  return dispatch_conv<false>(p, (hipStream_t)stream);
+}
+
+extern "C" size_t st_conv3x3_dgrad_workspace_bytes(int n, int cin, int h, int w, int pad_mode) {
+  if (pad_mode != ST_PAD_REPLICATE) return 0;
+  return size_t(n) * cin * (h + 2) * (w + 2) * sizeof(float);
+}
+
+extern "C" int st_conv3x3_dgrad(const float* dy, const float* y_gate, const float* w_packed_t,
+                                float* dx, float* workspace, int n, int cout, int h, int w,
+                                int cin, int upsample2x, int pad_mode, st_stream_t stream) {
+  ST_REQUIRE(dy && w_packed_t && dx, "st_conv3x3_dgrad: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0,
+             "st_conv3x3_dgrad: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO,
+             "st_conv3x3_dgrad: bad pad_mode %d", pad_mode);
+  ST_REQUIRE(!upsample2x || (h % 2 == 0 && w % 2 == 0),
+             "st_conv3x3_dgrad: upsampled layer needs even h, w (got %dx%d)", h, w);
+  ST_REQUIRE(!(upsample2x && pad_mode == ST_PAD_ZERO),
+             "st_conv3x3_dgrad: upsample2x is only supported with replicate padding");
+  ST_REQUIRE((long long)(h + 2) * (w + 2) < (1LL << 31), "st_conv3x3_dgrad: plane too large");
+  const bool rep = pad_mode == ST_PAD_REPLICATE;
+  ST_REQUIRE(!rep || workspace, "st_conv3x3_dgrad: replicate mode needs a workspace of "
+             "st_conv3x3_dgrad_workspace_bytes()");
   hipStream_t s = (hipStream_t)stream;
-  if (cout > 64) return launch_conv<2, 2, 2, 2>(p, s);   // 128 ch x (4 rows x 32)
-  if (cout > 32) return launch_conv<2, 2, 1, 4>(p, s);   //  64 ch x (8 rows x 32)
-  return launch_conv<1, 4, 1, 4>(p, s);                  //  32 ch x (16 rows x 32)
+  // The data gradient is itself a 3x3 correlation of (gated) dy with the transposed, rotated
+  // filter, zero padded.  With edge-replicate forward padding it is evaluated on the padded
+  // (h+2) x (w+2) domain and folded back onto the edges (and 2x2-summed for an upsample).
+  ConvParams p;
+  p.x = dy; p.gate = y_gate; p.wp = w_packed_t; p.bias = nullptr;
+  p.y = rep ? workspace : dx;
+  p.n = n; p.cin = cout; p.hs = h; p.ws = w; p.cout = cin;
+  p.up = 0; p.H = h; p.W = w;
+  p.Ho = rep ? h + 2 : h; p.Wo = rep ? w + 2 : w; p.shift = rep ? 1 : 0;
+  p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
+  p.nchunks = st::cdiv(cout, KC);
+  p.pad_zero = 1; p.relu = 0;
+  int rc = y_gate ? dispatch_conv<true>(p, s) : dispatch_conv<false>(p, s);
+  if (rc != ST_OK || !rep) return rc;
+  const int up = upsample2x ? 1 : 0;
+  const int hs = h >> up, ws = w >> up;
+  const long long total = (long long)n * cin * hs * ws;
+  const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 256 * 8);
+  hipLaunchKernelGGL(dgrad_fold_kernel, dim3(blocks), dim3(256), 0, s, workspace, dx, h, w, up,
+                     hs, ws, total);
+  return st::check_launch("st_conv3x3_dgrad(fold)");
 }

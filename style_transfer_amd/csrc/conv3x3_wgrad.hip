@@ -1,0 +1,304 @@
+// Weight (and bias) gradient of the fused [nearest x2 upsample] -> pad 1 -> Conv2d(3x3) -> [ReLU]
+// layer as an fp32 MFMA GEMM that reduces over pixels (decoder training: generator.py:85-130
+// trained by trainer.py:286-291, 471-473).
+//
+//   dW[o][c][tap] = sum_{n,y,x} G[n][o][y][x] * Xpad[n][c][y+ky-1][x+kx-1],   G = dy * (y > 0)
+//
+// GEMM view: D[o][j] = sum_pix G[o][pix] * Xp[pix][j],  j = c*9 + tap  (== the OIHW order, so an
+// accumulator register row is a contiguous run of dW).
+//   * v_mfma_f32_32x32x2_f32, M = output channels, N = (c, tap) columns, K = pixels.
+//   * A block (12 waves) owns 128 output channels x 32 input channels (288 = 9 x 32 columns) and
+//     walks a contiguous range of 64-pixel tiles (2 rows x 32); wave w owns channel tile w%4 and
+//     column tiles 3*(w/4)..+2: 3 accumulator tiles (48 registers), 1 A + 3 B reads per 3 MFMAs.
+//     The small register footprint lets two blocks (6 waves/SIMD) share a CU, so one block's
+//     staging hides under the other's MFMA phase.
+//   * LDS: gated dy tile [128][64 + 1] (odd stride: the A read walks channels), input halo
+//     [32][4 x 35 (+pad)] with row stride 35 and plane stride == 9 (mod 32), which puts the 32
+//     columns j of a B read on 32 distinct banks.
+//   * Split-K over pixel tiles: every block writes its partial slab; a second kernel sums the
+//     slabs in a fixed order (deterministic, no float atomics).  The bias gradient is the row sum
+//     of G, accumulated while staging.
+#include <algorithm>
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NTHREADS = 768;      // 12 waves
+constexpr int BO = 128;           // output channels per block
+constexpr int CI = 32;            // input channels per block -> 288 columns = 9 MFMA tiles
+constexpr int NJT = 9;
+constexpr int WJT = 3;            // column tiles per wave
+constexpr int TR = 2;             // pixel-tile rows
+constexpr int TW = 32;            // pixel-tile width
+constexpr int TP = TR * TW;       // 64 pixels = 32 MFMA k-steps
+constexpr int GS = TP + 1;        // odd row stride of the dy tile
+constexpr int HC = 35;            // halo row stride (== 3 mod 32)
+constexpr int HR = TR + 2;
+constexpr int PLANE = 169;        // >= HR*HC = 140 and == 9 (mod 32)
+constexpr int G_ELEMS = BO * GS;
+constexpr int X_ELEMS = CI * PLANE;
+constexpr int NXP = (CI * HR * (TW + 2) + NTHREADS - 1) / NTHREADS;   // halo loads per thread
+constexpr int NG4 = BO * TR * (TW / 4);                                // float4 of one dy tile
+constexpr int NGP = (NG4 + NTHREADS - 1) / NTHREADS;
+constexpr size_t LDS_BYTES = size_t(G_ELEMS + X_ELEMS) * sizeof(float);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+  const float* dy;      // [n][cout][H][W]
+  const float* ygate;   // nullable, same shape: dy counts only where ygate > 0
+  const float* x;       // [n][cin][hs][ws]
+  float* slabs;         // [nsplit][cout][cin*9]
+  float* bias_slabs;    // [nsplit][cout] (nullable)
+  int n, cout, cin, hs, ws, H, W;
+  int up, pad_zero;
+  int tiles_x, tiles_y, ntiles;   // pixel tiles per image / total
+  int tiles_per_split, nsplit;
+};
+
+template <bool GATE>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Gs = smem;
+  float* Xs = smem + G_ELEMS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int c0 = blockIdx.x * CI;
+  const int o0 = blockIdx.y * BO;
+  const int split = blockIdx.z;
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
+
+  // ---- staging maps ----------------------------------------------------------------------
+  // dy tile = 256 row segments (128 channels x 2 tile rows) of 32 pixels = 8 float4.  Eight
+  // consecutive lanes cover one 128-B segment, so a wave instruction reads 8 whole lines.
+  // float4 index g = tid + i*768 -> segment r = g/8 (channel r>>1, tile row r&1), float4 q = g%8.
+  const int gq = tid & 7, gr0 = tid >> 3;
+  const bool vec4 = (p.W & 3) == 0;   // rows 16-B aligned (the entry point checks the bases)
+  // halo: element e = tid + i*256 of a [CI][HR][TW+2] box, packed as
+  //   bits 0..12 LDS offset, 16..17 row, 20..25 col, 26..30 channel
+  unsigned xinfo[NXP];
+#pragma unroll
+  for (int i = 0; i < NXP; ++i) {
+    const int e = min(tid + i * NTHREADS, CI * HR * (TW + 2) - 1);
+    const int c = e / (HR * (TW + 2));
+    const int rem = e - c * (HR * (TW + 2));
+    const int row = rem / (TW + 2), col = rem - row * (TW + 2);
+    xinfo[i] = unsigned(c * PLANE + row * HC + col) | (row << 16) | (col << 20) | (c << 26);
+  }
+  const size_t plane_src = size_t(p.hs) * p.ws;
+  const size_t plane_out = size_t(p.H) * p.W;
+
+  f32x16 acc[WJT];
+#pragma unroll
+  for (int t = 0; t < WJT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bias_acc[NGP];
+#pragma unroll
+  for (int i = 0; i < NGP; ++i) bias_acc[i] = 0.f;
+
+  // per-lane operand bases.  A: Gs[(ot*32 + li)][pix]; B: column j = jt*32 + li -> (c, tap)
+  const int ot = wave & 3, jt0 = (wave >> 2) * WJT;
+  const float* aPtr = Gs + (ot * 32 + li) * GS + lh;
+  int bOff[WJT];
+#pragma unroll
+  for (int jt = 0; jt < WJT; ++jt) {
+    const int j = (jt0 + jt) * 32 + li;
+    const int c = j / 9, tap = j - c * 9;
+    bOff[jt] = c * PLANE + (tap / 3) * HC + (tap % 3) + lh;
+  }
+
+  for (int t = t_begin; t < t_end; ++t) {
+    int rem = t;
+    const int tx = rem % p.tiles_x;
+    rem /= p.tiles_x;
+    const int ty = rem % p.tiles_y;
+    const int b = rem / p.tiles_y;
+    const int x0 = tx * TW, y0 = ty * TR;
+
+    // -- global loads (unconditional, clamped addresses) --
+    f32x4 gv[NGP];
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+      const int r = min(gr0 + (NTHREADS / 8) * i, BO * TR - 1);   // tail threads re-load the last segment
+      const int o = min(o0 + (r >> 1), p.cout - 1);
+      const int cy = min(y0 + (r & 1), p.H - 1);
+      const size_t base = (size_t(b) * p.cout + o) * plane_out + size_t(cy) * p.W;
+      if (vec4) {
+        const int cx = min(x0 + gq * 4, p.W - 4);
+        gv[i] = *reinterpret_cast<const f32x4*>(p.dy + base + cx);
+        if (GATE) {
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(p.ygate + base + cx);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gv[i][k] = yv[k] > 0.f ? gv[i][k] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int cx = min(x0 + gq * 4 + k, p.W - 1);
+          gv[i][k] = p.dy[base + cx];
+          if (GATE) gv[i][k] = p.ygate[base + cx] > 0.f ? gv[i][k] : 0.f;
+        }
+      }
+    }
+    float xv[NXP];
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+      const int row = (xinfo[i] >> 16) & 3, col = (xinfo[i] >> 20) & 63, c = xinfo[i] >> 26;
+      int cy = min(max(y0 + row - 1, 0), p.H - 1), cx = min(max(x0 + col - 1, 0), p.W - 1);
+      if (p.up) { cy >>= 1; cx >>= 1; }
+      xv[i] = p.x[(size_t(b) * p.cin + min(c0 + c, p.cin - 1)) * plane_src + size_t(cy) * p.ws + cx];
+    }
+
+    __syncthreads();   // previous tile's MFMA phase is done with LDS
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+      const int r = gr0 + (NTHREADS / 8) * i;
+      if (NG4 % NTHREADS != 0 && r >= BO * TR) break;
+      const bool row_ok = (o0 + (r >> 1)) < p.cout && (y0 + (r & 1)) < p.H;
+      float* dst = Gs + (r >> 1) * GS + (r & 1) * TW + gq * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float g = (row_ok && (x0 + gq * 4 + k) < p.W) ? gv[i][k] : 0.f;
+        dst[k] = g;
+        bias_acc[i] += g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+      const int e = tid + i * NTHREADS;
+      const int row = (xinfo[i] >> 16) & 3, col = (xinfo[i] >> 20) & 63, c = xinfo[i] >> 26;
+      const int gy = y0 + row - 1, gx = x0 + col - 1;
+      const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const unsigned m = ((inb || !p.pad_zero) && (c0 + c) < p.cin) ? 0xffffffffu : 0u;
+      if (e < CI * HR * (TW + 2)) Xs[xinfo[i] & 0x1fff] = __uint_as_float(__float_as_uint(xv[i]) & m);
+    }
+    __syncthreads();
+
+    // -- 32 k-steps of 2 pixels: pixel 2s+lh = (row, col) of the tile --
+#pragma unroll
+    for (int s = 0; s < TP / 2; ++s) {
+      const int row = (2 * s) / TW, col = (2 * s) % TW;
+      const float a = aPtr[2 * s];
+      const int poff = row * HC + col;
+#pragma unroll
+      for (int jt = 0; jt < WJT; ++jt) {
+        const float bv = Xs[bOff[jt] + poff];
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[jt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: partial slab, register row r = one output channel, 32 contiguous columns --
+  float* slab = p.slabs + size_t(split) * p.cout * p.cin * 9;
+#pragma unroll
+  for (int jt = 0; jt < WJT; ++jt) {
+    const int jg = c0 * 9 + (jt0 + jt) * 32 + li;     // column in the [cin*9] row
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (o < p.cout && jg < p.cin * 9) slab[size_t(o) * p.cin * 9 + jg] = acc[jt][r];
+    }
+  }
+  if (p.bias_slabs && blockIdx.x == 0) {
+    // a channel's 2 segments x 8 float4 sit in 16 consecutive lanes (tid/8 = 2*ch + row)
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+      float v = bias_acc[i];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      const int r = gr0 + (NTHREADS / 8) * i;
+      const int o = o0 + (r >> 1);
+      if ((tid & 15) == 0 && r < BO * TR && o < p.cout) p.bias_slabs[size_t(split) * p.cout + o] = v;
+    }
+  }
+}
+
+// out[e] = sum_s slabs[s][e], fixed order.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs,
+                                                         float* __restrict__ out, long long n,
+                                                         int nsplit) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slabs[(size_t)k * n + e];
+    out[e] = s;
+  }
+}
+
+struct Plan {
+  int tiles_x, tiles_y, ntiles, nsplit, tiles_per_split;
+};
+
+Plan make_plan(int n, int cout, int cin, int H, int W) {
+  Plan pl;
+  pl.tiles_x = st::cdiv(W, TW);
+  pl.tiles_y = st::cdiv(H, TR);
+  const long long nt = (long long)n * pl.tiles_x * pl.tiles_y;
+  pl.ntiles = (int)std::min<long long>(nt, 0x7fffffff);
+  const int ctiles = st::cdiv(cin, CI) * st::cdiv(cout, BO);
+  // aim for ~4 blocks per CU (2 resident), but keep >= 4 pixel tiles per block
+  int want = std::max(1, (256 * 4) / ctiles);   // ~2 resident blocks per CU, two waves of them
+  int nsplit = std::max(1, std::min(want, pl.ntiles / 4));
+  nsplit = std::min(nsplit, 512);
+  pl.tiles_per_split = st::cdiv(pl.ntiles, nsplit);
+  pl.nsplit = st::cdiv(pl.ntiles, pl.tiles_per_split);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t st_conv3x3_wgrad_workspace_bytes(int n, int cout, int cin, int h, int w) {
+  if (n <= 0 || cout <= 0 || cin <= 0 || h <= 0 || w <= 0) return 0;
+  const Plan pl = make_plan(n, cout, cin, h, w);
+  return size_t(pl.nsplit) * (size_t(cout) * cin * 9 + cout) * sizeof(float);
+}
+
+extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_gate, float* dw,
+                                float* dbias, float* workspace, int n, int cin, int hin, int win,
+                                int cout, int upsample2x, int pad_mode, st_stream_t stream) {
+  ST_REQUIRE(x && dy && dw && workspace, "st_conv3x3_wgrad: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
+             "st_conv3x3_wgrad: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO,
+             "st_conv3x3_wgrad: bad pad_mode %d", pad_mode);
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(dy) % 16 == 0 &&
+             (!y_gate || reinterpret_cast<uintptr_t>(y_gate) % 16 == 0),
+             "st_conv3x3_wgrad: dy / y_gate must be 16-byte aligned");
+  const int up = upsample2x ? 1 : 0;
+  const int H = hin << up, W = win << up;
+  ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, TR) <= 0x7fffffffLL,
+             "st_conv3x3_wgrad: too many pixel tiles");
+  const Plan pl = make_plan(n, cout, cin, H, W);
+  WgradParams p;
+  p.dy = dy; p.ygate = y_gate; p.x = x;
+  p.slabs = workspace;
+  p.bias_slabs = dbias ? workspace + size_t(pl.nsplit) * cout * cin * 9 : nullptr;
+  p.n = n; p.cout = cout; p.cin = cin; p.hs = hin; p.ws = win; p.H = H; p.W = W;
+  p.up = up; p.pad_zero = pad_mode == ST_PAD_ZERO;
+  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
+  p.tiles_per_split = pl.tiles_per_split; p.nsplit = pl.nsplit;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(st::cdiv(cin, CI), st::cdiv(cout, BO), pl.nsplit);
+  if (y_gate)
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<true>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
+  else
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<false>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
+  int rc = st::check_launch("st_conv3x3_wgrad");
+  if (rc != ST_OK) return rc;
+  const long long nw = (long long)cout * cin * 9;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(nw, 256), 2048)),
+                     dim3(256), 0, s, p.slabs, dw, nw, pl.nsplit);
+  if (dbias)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(st::cdiv(cout, 256)), dim3(256), 0, s,
+                       p.bias_slabs, dbias, (long long)cout, pl.nsplit);
+  return st::check_launch("st_conv3x3_wgrad(reduce)");
+}

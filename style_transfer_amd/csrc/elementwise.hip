@@ -51,6 +51,42 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict
   }
 }
 
+// Backward of the 2x2/2 max pool: each thread owns one (ceil-mode) window of x, routes dy to
+// the first maximum in scan order (torch's tie rule: strictly-greater replaces) and zeroes the
+// rest, so dx is written exactly once everywhere (floor-mode remainders get 0).
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int h, int w,
+                                                            int ho, int wo, int hc, int wc,
+                                                            long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ox = int(e % wc);
+    long long t = e / wc;
+    const int oy = int(t % hc);
+    const long long plane = t / hc;
+    const float* xp = x + plane * h * w;
+    float* dp = dx + plane * h * w;
+    const int iy = oy * 2, ix = ox * 2;
+    const bool y1 = iy + 1 < h, x1 = ix + 1 < w;
+    const float g = (oy < ho && ox < wo) ? dy[(plane * ho + oy) * wo + ox] : 0.f;
+    float m = xp[(size_t)iy * w + ix];
+    int arg = 0;
+    if (x1) { const float v = xp[(size_t)iy * w + ix + 1]; if (v > m || v != v) { m = v; arg = 1; } }
+    if (y1) {
+      const float v = xp[(size_t)(iy + 1) * w + ix];
+      if (v > m || v != v) { m = v; arg = 2; }
+      if (x1) { const float v2 = xp[(size_t)(iy + 1) * w + ix + 1]; if (v2 > m || v2 != v2) { m = v2; arg = 3; } }
+    }
+    dp[(size_t)iy * w + ix] = arg == 0 ? g : 0.f;
+    if (x1) dp[(size_t)iy * w + ix + 1] = arg == 1 ? g : 0.f;
+    if (y1) {
+      dp[(size_t)(iy + 1) * w + ix] = arg == 2 ? g : 0.f;
+      if (x1) dp[(size_t)(iy + 1) * w + ix + 1] = arg == 3 ? g : 0.f;
+    }
+  }
+}
+
 inline int grid_for(long long total) {
   return (int)std::max<long long>(1, std::min<long long>(st::cdivll(total, 256), 256 * 8));
 }
@@ -77,6 +113,19 @@ extern "C" int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w,
   hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                      x, y, h, w, ho, wo, total);
   return st::check_launch("st_maxpool2x2_fwd");
+}
+
+extern "C" int st_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,
+                                 int ceil_mode, st_stream_t stream) {
+  ST_REQUIRE(x && dy && dx, "st_maxpool2x2_bwd: null pointer");
+  ST_REQUIRE(nc > 0 && h > 0 && w > 0, "st_maxpool2x2_bwd: bad dims nc=%d h=%d w=%d", nc, h, w);
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
+  const int ho = ceil_mode ? hc : h / 2, wo = ceil_mode ? wc : w / 2;
+  ST_REQUIRE(ho > 0 && wo > 0, "st_maxpool2x2_bwd: empty output for %dx%d floor mode", h, w);
+  const long long total = (long long)nc * hc * wc;
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     (hipStream_t)stream, x, dy, dx, h, w, ho, wo, hc, wc, total);
+  return st::check_launch("st_maxpool2x2_bwd");
 }
 
 // ---- SymmetricPadding2D, any (left, right, top, bottom) (generator.py:14-39) -------------

@@ -97,6 +97,65 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     return y
 
 
+def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: torch.Tensor, cin: int,
+                  upsample2x: bool = False, pad_mode="replicate") -> torch.Tensor:
+    """Gradient w.r.t. the input of the fused conv layer; ``y_gate`` = its post-ReLU output (or None)."""
+    lib = _lib.load()
+    n, cout, h, w = (int(v) for v in dy.shape)
+    pm = _pad_code(pad_mode)
+    s = 2 if upsample2x else 1
+    dx = torch.empty((n, cin, h // s, w // s), dtype=torch.float32, device=dy.device)
+    nbytes = lib.st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, pm)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device) if nbytes else None
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cin) + " dgrad", 2.0 * n * h * w * cin * cout * 9,
+                                 4.0 * (dy.numel() + dx.numel()))
+    _lib.check(lib.st_conv3x3_dgrad(_lib.dev_ptr(dy, "dy"),
+                                    _lib.dev_ptr(y_gate, "y_gate") if y_gate is not None else None,
+                                    _lib.dev_ptr(w_packed_t, "w_packed_t"), _lib.dev_ptr(dx, "dx"),
+                                    _lib.dev_ptr(ws, "workspace") if ws is not None else None,
+                                    n, cout, h, w, cin, int(upsample2x), pm, _lib.stream_ptr()), "st_conv3x3_dgrad")
+    if ev is not None:
+        ev.record()
+    return dx
+
+
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tensor], want_bias: bool = True,
+                  upsample2x: bool = False, pad_mode="replicate") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """(dW [cout,cin,3,3], dbias [cout] or None) of the fused conv layer."""
+    lib = _lib.load()
+    n, cin, h, w = (int(v) for v in x.shape)
+    cout = int(dy.shape[1])
+    s = 2 if upsample2x else 1
+    assert tuple(dy.shape) == (n, cout, h * s, w * s), f"dy shape {tuple(dy.shape)} does not match x {tuple(x.shape)}"
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    nbytes = lib.st_conv3x3_wgrad_workspace_bytes(n, cout, cin, h * s, w * s)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record("conv3x3_wgrad_kernel", 2.0 * n * h * s * w * s * cin * cout * 9,
+                                 4.0 * (dy.numel() + x.numel()))
+    _lib.check(lib.st_conv3x3_wgrad(_lib.dev_ptr(x, "x"), _lib.dev_ptr(dy, "dy"),
+                                    _lib.dev_ptr(y_gate, "y_gate") if y_gate is not None else None,
+                                    _lib.dev_ptr(dw, "dw"), _lib.dev_ptr(db, "db") if db is not None else None,
+                                    _lib.dev_ptr(ws, "workspace"), n, cin, h, w, cout, int(upsample2x),
+                                    _pad_code(pad_mode), _lib.stream_ptr()), "st_conv3x3_wgrad")
+    if ev is not None:
+        ev.record()
+    return dw, db
+
+
+def maxpool2x2_bwd(x: torch.Tensor, dy: torch.Tensor, ceil_mode: bool) -> torch.Tensor:
+    lib = _lib.load()
+    n, c, h, w = (int(v) for v in x.shape)
+    dx = torch.empty_like(x)
+    _lib.check(lib.st_maxpool2x2_bwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(dy, "dy"), _lib.dev_ptr(dx, "dx"), n * c, h, w,
+                                     int(ceil_mode), _lib.stream_ptr()), "st_maxpool2x2_bwd")
+    return dx
+
+
 def sympad(x: torch.Tensor, padding=(1, 1, 1, 1)) -> torch.Tensor:
     """SymmetricPadding2D.forward (generator.py:19-39); padding = (left, right, top, bottom)."""
     lib = _lib.load()
