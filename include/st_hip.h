@@ -126,10 +126,46 @@ int st_adain_fwd(const float* content, const float* style, float* out,
                  float eps_content, float eps_style, float alpha,
                  float* stats, st_stream_t stream);
 
+/* AdaIN backward.  gout: [n][c][hw_content] gradient of `out`; stats: as saved by st_adain_fwd.
+ * dcontent / dstyle: nullable (the training loop needs neither: the encoder is frozen).
+ * deps[2] = {d/d eps_content, d/d eps_style} (the trainable eps of transformer.py:11-12, before
+ * the sqrt(|p|) of adjust_sigmoid).  workspace: n*c*2 floats. */
+int st_adain_bwd(const float* gout, const float* content, const float* style, const float* stats,
+                 float alpha, float* dcontent, float* dstyle, float* deps, float* workspace,
+                 int n, int c, int hw_content, int hw_style, st_stream_t stream);
+
 /* per-plane mean and sqrt(unbiased var + eps)  (AdaIN.calc_mean_std transformer.py:15-24,
  * AdaINStyleLoss.calc_mean_std losses.py:20-28).  mean, std: [planes] */
 int st_meanstd_fwd(const float* x, float* mean, float* std, int planes, int hw, float eps,
                    st_stream_t stream);
+
+/* ---- loss reductions (fixed-order two-stage sums; `workspace` >= st_reduce_workspace_bytes()).
+ * Backward entry points take the upstream gradient as a DEVICE scalar `gout` (NULL = 1) times
+ * the host `scale`, and overwrite (accumulate = 0) or add into (accumulate = 1) dx. ------------ */
+size_t st_reduce_workspace_bytes(void);
+
+/* nn.MSELoss: AdaINContentLoss.forward (losses.py:93-101).  out[0] = mean((a-b)^2);
+ * da (+)= gout*scale * 2 (a-b) / n. */
+int st_mse_fwd(const float* a, const float* b, long long n, float* workspace, float* out,
+               st_stream_t stream);
+int st_mse_bwd(const float* a, const float* b, const float* gout, float scale, float* da,
+               long long n, int accumulate, st_stream_t stream);
+
+/* TVLoss.forward (losses.py:104-116) on x [n][c][h][w]. */
+int st_tv_fwd(const float* x, int n, int c, int h, int w, float* workspace, float* out,
+              st_stream_t stream);
+int st_tv_bwd(const float* x, const float* gout, float scale, float* dx, int n, int c, int h, int w,
+              int accumulate, st_stream_t stream);
+
+/* AdaINStyleLoss.calc_style_loss (losses.py:30-36) from per-plane stats (st_meanstd_fwd, eps 1e-5):
+ * out[0] = mean((mean_a-mean_b)^2) + mean((std_a-std_b)^2); bwd w.r.t. the feature map x that
+ * produced (mean_a, std_a). */
+int st_meanstd_loss_fwd(const float* mean_a, const float* std_a, const float* mean_b,
+                        const float* std_b, int planes, float* workspace, float* out,
+                        st_stream_t stream);
+int st_meanstd_loss_bwd(const float* x, const float* mean_a, const float* std_a, const float* mean_b,
+                        const float* std_b, const float* gout, float scale, float* dx, int planes,
+                        int hw, int accumulate, st_stream_t stream);
 
 #ifdef __cplusplus
 }

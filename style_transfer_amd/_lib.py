@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p
 
 import torch
 
@@ -34,6 +34,16 @@ SIGNATURES = {
     "st_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_adain_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                              c_float, c_void_p, c_void_p]),
+    "st_adain_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_int, c_int, c_int, c_int, c_void_p]),
+    "st_reduce_workspace_bytes": (c_size_t, []),
+    "st_mse_fwd": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
+    "st_mse_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong, c_int, c_void_p]),
+    "st_tv_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "st_tv_bwd": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_meanstd_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "st_meanstd_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                    c_int, c_int, c_int, c_void_p]),
     "st_meanstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
 }
 

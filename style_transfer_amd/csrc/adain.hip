@@ -162,7 +162,83 @@ __global__ __launch_bounds__(NT) void meanstd_kernel(const float* __restrict__ x
   }
 }
 
+// ---- backward --------------------------------------------------------------------------
+// out = alpha * ((x - mu_c)/sg_c * sg_s + mu_s) + (1 - alpha) * x,  sg = sqrt(var_unbiased + eps).
+// Per plane: S0 = sum g, S1 = sum g*xhat; then
+//   d eps_c  = -alpha * sg_s * S1 / (2 sg_c^2)          d eps_s = alpha * S1 / (2 sg_s)
+//   dx_j     = alpha*sg_s/sg_c * (g_j - S0/n - xhat_j*S1/(n-1)) + (1-alpha) g_j
+//   dstyle_i = alpha * (S0/n_s + S1 * (s_i - mu_s) / ((n_s-1) sg_s))
+__global__ __launch_bounds__(NT) void adain_bwd_kernel(const float* __restrict__ gout,
+                                                      const float* __restrict__ content,
+                                                      const float* __restrict__ style,
+                                                      const float* __restrict__ stats, float alpha,
+                                                      float* __restrict__ dcontent,
+                                                      float* __restrict__ dstyle,
+                                                      float* __restrict__ deps_part, int hw_c, int hw_s) {
+  __shared__ float red[NT / 64];
+  const size_t plane = blockIdx.x;
+  const float mu_c = stats[plane * 4 + 0], sg_c = stats[plane * 4 + 1];
+  const float mu_s = stats[plane * 4 + 2], sg_s = stats[plane * 4 + 3];
+  const float* gp = gout + plane * hw_c;
+  const float* xp = content + plane * hw_c;
+  const float inv_c = 1.f / sg_c;
+  float s0 = 0.f, s1 = 0.f;
+  for (int i = threadIdx.x; i < hw_c; i += NT) {
+    const float g = gp[i];
+    s0 += g;
+    s1 += g * ((xp[i] - mu_c) * inv_c);
+  }
+  s0 = st::block_sum<NT>(s0, red);
+  s1 = st::block_sum<NT>(s1, red);
+  if (threadIdx.x == 0) {
+    deps_part[plane * 2 + 0] = -alpha * sg_s * s1 * 0.5f * inv_c * inv_c;
+    deps_part[plane * 2 + 1] = alpha * s1 * 0.5f / sg_s;
+  }
+  if (dcontent) {
+    float* dp = dcontent + plane * hw_c;
+    const float a = alpha * sg_s * inv_c, beta = 1.f - alpha;
+    const float m0 = s0 / float(hw_c), m1 = s1 / float(hw_c - 1);
+    for (int i = threadIdx.x; i < hw_c; i += NT) {
+      const float g = gp[i];
+      dp[i] = a * (g - m0 - (xp[i] - mu_c) * inv_c * m1) + beta * g;
+    }
+  }
+  if (dstyle) {
+    const float* sp = style + plane * hw_s;
+    float* dp = dstyle + plane * hw_s;
+    const float k0 = alpha * s0 / float(hw_s), k1 = alpha * s1 / (float(hw_s - 1) * sg_s);
+    for (int i = threadIdx.x; i < hw_s; i += NT) dp[i] = k0 + k1 * (sp[i] - mu_s);
+  }
+}
+
+// deps[k] = sum over planes of deps_part[plane][k], fixed order
+__global__ __launch_bounds__(NT) void deps_reduce_kernel(const float* __restrict__ part, int planes,
+                                                        float* __restrict__ deps) {
+  __shared__ float red[NT / 64];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < planes; i += NT) { a += part[(size_t)i * 2]; b += part[(size_t)i * 2 + 1]; }
+  a = st::block_sum<NT>(a, red);
+  b = st::block_sum<NT>(b, red);
+  if (threadIdx.x == 0) { deps[0] = a; deps[1] = b; }
+}
+
 }  // namespace
+
+extern "C" int st_adain_bwd(const float* gout, const float* content, const float* style,
+                            const float* stats, float alpha, float* dcontent, float* dstyle,
+                            float* deps, float* workspace, int n, int c, int hw_content, int hw_style,
+                            st_stream_t stream) {
+  ST_REQUIRE(gout && content && style && stats && deps && workspace, "st_adain_bwd: null pointer");
+  ST_REQUIRE(n > 0 && c > 0 && hw_content > 0 && hw_style > 0,
+             "st_adain_bwd: bad dims n=%d c=%d hw_c=%d hw_s=%d", n, c, hw_content, hw_style);
+  const long long planes = (long long)n * c;
+  ST_REQUIRE(planes <= 0x7fffffffLL, "st_adain_bwd: too many planes");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adain_bwd_kernel, dim3((unsigned)planes), dim3(NT), 0, s, gout, content, style, stats,
+                     alpha, dcontent, dstyle, workspace, hw_content, hw_style);
+  hipLaunchKernelGGL(deps_reduce_kernel, dim3(1), dim3(NT), 0, s, workspace, (int)planes, deps);
+  return st::check_launch("st_adain_bwd");
+}
 
 extern "C" int st_adain_fwd(const float* content, const float* style, float* out, int n, int c,
                             int hw_content, int hw_style, float eps_content, float eps_style,

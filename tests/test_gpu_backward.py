@@ -89,3 +89,58 @@ def test_decoder_autograd_golden(golden_dir):
     assert rel_err(dec.decoder[1].weight.grad[:8, :16], torch.from_numpy(g["g_dw1_slice"])) < 1e-3
     assert rel_err(dec.decoder[1].bias.grad, torch.from_numpy(g["g_db1"])) < 1e-3
     assert rel_err(dec.decoder[18].weight.grad[:8, :16], torch.from_numpy(g["g_dw18_slice"])) < 1e-3
+
+
+# ---- AdaIN backward + simple losses against the reference-generated golden vectors ----------------
+@pytest.mark.parametrize("tag,lim", [("1e-5", 1e-5), ("0.1", 0.1), ("0.3", 0.3)])
+def test_adain_module_golden(golden_dir, tag, lim):
+    from style_transfer_amd.transformer import AdaIN
+    g = np.load(os.path.join(golden_dir, "adain.npz"))
+    m = AdaIN(eps=lim).cuda()
+    with torch.no_grad():
+        m.content_eps.fill_(4e-4)
+        m.style_eps.fill_(2.5e-3)
+    c = torch.from_numpy(g["content"]).cuda().requires_grad_(True)
+    s = torch.from_numpy(g["style"]).cuda().requires_grad_(True)
+    o = m(c, s)
+    (o * torch.from_numpy(g["gup"]).cuda()).sum().backward()
+    assert rel_err(o, torch.from_numpy(g[f"out_{tag}"])) < 1e-5
+    assert rel_err(c.grad, torch.from_numpy(g[f"dcontent_{tag}"])) < 1e-4
+    assert rel_err(s.grad, torch.from_numpy(g[f"dstyle_{tag}"])) < 1e-4
+    for p, key in ((m.content_eps, f"dceps_{tag}"), (m.style_eps, f"dseps_{tag}")):
+        ref = float(g[key][0])
+        got = float(p.grad[0]) if p.grad is not None else 0.0
+        assert got == pytest.approx(ref, rel=1e-3, abs=1e-6)
+    eps = m.get_current_eps()
+    np.testing.assert_allclose(eps, g[f"eps_{tag}"], rtol=1e-6)
+
+
+def test_simple_losses_golden(golden_dir):
+    from style_transfer_amd.losses import AdaINContentLoss, AdaINStyleLoss, TVLoss
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+
+    def run(mod, x, *rest):
+        xx = torch.from_numpy(x).cuda().requires_grad_(True)
+        v = mod(xx, *[torch.from_numpy(r).cuda() for r in rest])
+        v.backward()
+        return v, xx.grad
+
+    v, d = run(AdaINStyleLoss(), g["a"], g["b"])
+    assert float(v) == pytest.approx(float(g["adain_style"]), rel=1e-5)
+    assert rel_err(d, torch.from_numpy(g["adain_style_da"])) < 1e-4
+    v, d = run(AdaINContentLoss(), g["a"], g["b"])
+    assert float(v) == pytest.approx(float(g["content"]), rel=1e-5)
+    assert rel_err(d, torch.from_numpy(g["content_da"])) < 1e-5
+    v, d = run(TVLoss(), g["img"])
+    assert float(v) == pytest.approx(float(g["tv"]), rel=1e-5)
+    assert rel_err(d, torch.from_numpy(g["tv_dimg"])) < 1e-5
+
+
+def test_tv_known_answer(golden_dir):
+    from style_transfer_amd.losses import TVLoss
+    kat = np.load(os.path.join(golden_dir, "kat.npz"))
+    torch.manual_seed(0)
+    img = torch.rand(8, 3, 256, 256)
+    assert float(TVLoss()(img.cuda())) == pytest.approx(float(kat["tv"]), rel=1e-5)     # 66.6369...
+    one_row = torch.rand(1, 3, 1, 9, generator=torch.Generator().manual_seed(1))
+    assert float(TVLoss()(one_row.cuda())) == pytest.approx(float(R.tv_loss(one_row)), rel=1e-5)

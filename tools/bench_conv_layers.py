@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     args = ap.parse_args()
     dev = torch.device("cuda")
     tot_t = tot_f = 0.0
@@ -39,12 +40,21 @@ def main():
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         b = torch.randn(cout, device=dev)
         wp = ops.pack_conv3x3_weights(w)
-        ops.conv3x3(x, wp, b, cout, upsample2x=up)
+        y = ops.conv3x3(x, wp, b, cout, upsample2x=up)
+        dy = torch.randn_like(y)
+        wpt = ops.pack_conv3x3_weights(w, transpose_flip=True)
+        if args.mode == "fwd":
+            fn = lambda: ops.conv3x3(x, wp, b, cout, upsample2x=up)
+        elif args.mode == "dgrad":
+            fn = lambda: ops.conv3x3_dgrad(dy, y, wpt, cin, up, "replicate")
+        else:
+            fn = lambda: ops.conv3x3_wgrad(x, dy, y, True, up, "replicate")
+        fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
-            ops.conv3x3(x, wp, b, cout, upsample2x=up)
+            fn()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
