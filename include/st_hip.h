@@ -108,6 +108,12 @@ int st_sympad_fwd(const float* x, float* y, int nc, int h, int w, int left, int 
 int st_conv1x1_3to3_fwd(const float* x, const float* w /*[3][3]*/, const float* b /*[3]*/,
                         float* y, int n, int hw, st_stream_t stream);
 
+/* ---- transforms.Normalize (trainer.py:299, 440-442, 707-708): y = (x - mean[c]) / std[c].
+ * mean_host / std_host: HOST arrays of c <= 8 floats (mean_host NULL = 0, which makes this the
+ * backward as well: dx = dy / std). */
+int st_normalize_fwd(const float* x, float* y, int n, int c, int hw, const float* mean_host,
+                     const float* std_host, st_stream_t stream);
+
 /* ---- 2x2 stride-2 max pool (generator.py:53,60,73; torchvision vgg19 'M') ------------- */
 int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, int ceil_mode,
                       st_stream_t stream);

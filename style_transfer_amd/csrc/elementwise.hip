@@ -164,3 +164,38 @@ extern "C" int st_sympad_fwd(const float* x, float* y, int nc, int h, int w, int
                      h, w, left, top, ho, wo, total);
   return st::check_launch("st_sympad_fwd");
 }
+
+// ---- transforms.Normalize(mean, std) on [n][c][hw] (trainer.py:299, 440-442, 707-708) ----------
+namespace {
+
+struct NormArgs {
+  float mean[8];
+  float inv_std[8];
+};
+
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int c, long long hw, long long total, NormArgs a) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ch = int((e / hw) % c);
+    y[e] = (x[e] - a.mean[ch]) * a.inv_std[ch];
+  }
+}
+
+}  // namespace
+
+extern "C" int st_normalize_fwd(const float* x, float* y, int n, int c, int hw, const float* mean_host,
+                                const float* std_host, st_stream_t stream) {
+  ST_REQUIRE(x && y && std_host, "st_normalize_fwd: null pointer");
+  ST_REQUIRE(n > 0 && c > 0 && c <= 8 && hw > 0, "st_normalize_fwd: bad dims n=%d c=%d hw=%d", n, c, hw);
+  NormArgs a;
+  for (int i = 0; i < c; ++i) {
+    a.mean[i] = mean_host ? mean_host[i] : 0.f;
+    ST_REQUIRE(std_host[i] != 0.f, "st_normalize_fwd: std[%d] == 0", i);
+    a.inv_std[i] = 1.f / std_host[i];
+  }
+  const long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, c,
+                     (long long)hw, total, a);
+  return st::check_launch("st_normalize_fwd");
+}

@@ -1,0 +1,152 @@
+"""The perceptual loss network of the training step: torchvision ``vgg19().features`` truncated
+at the last requested layer, every Conv2d under weight_norm, read through an
+IntermediateLayerGetter (src/models/trainer.py:165-199, used at :446-457), on HIP kernels.
+
+torchvision is not a dependency here: the VGG19 "E" layout is restated (3x3 convs with zero
+padding 1, ReLU(inplace=True), floor-mode 2x2 max pools; indices 0..36).  Each
+Conv2d -> ReLU pair is one fused MFMA launch.  Because torchvision's ReLUs are in-place, the
+tensor a caller captured at a conv index has been overwritten by the following ReLU by the time
+``forward`` returns -- unless that conv is the last layer kept.  ``forward`` reproduces exactly
+that: captured conv outputs are post-ReLU, except when the conv is the final layer.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from collections import OrderedDict
+from typing import Dict, List, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .autograd import _needs_grad, conv3x3_apply, maxpool2x2_apply
+from .generator import _PackedWeightCache
+
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def vgg19_layers():
+    """[(kind, cin, cout)] for torchvision vgg19().features indices 0..36."""
+    layers, cin = [], 3
+    for v in VGG19_CFG:
+        if v == "M":
+            layers.append(("pool", 0, 0))
+        else:
+            layers.append(("conv", cin, int(v)))
+            layers.append(("relu", 0, 0))
+            cin = int(v)
+    return layers
+
+
+class _NormalizeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean, std):
+        ctx.std = std
+        return ops.normalize(x, mean, std)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.normalize(g.contiguous(), None, ctx.std), None, None
+
+
+class Normalize(nn.Module):
+    """transforms.Normalize(mean, std) for batched NCHW tensors (trainer.py:299)."""
+
+    def __init__(self, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+        super().__init__()
+        self.mean, self.std = tuple(mean), tuple(std)
+
+    def forward(self, x):
+        x = x.contiguous()
+        if _needs_grad(x):
+            return _NormalizeFunction.apply(x, self.mean, self.std)
+        return ops.normalize(x, self.mean, self.std)
+
+
+class VGG19FeatureExtractor(nn.Module):
+    """``Trainer.get_feature_extractor(selected_indices)`` (trainer.py:165-199).
+
+    ``forward(x)`` returns an OrderedDict in layer order, one tensor per requested index (keys are
+    the index as a string); ``list(extractor(x).values())`` is what the reference's loop reads.
+    The network is frozen (it is in no optimizer): only data gradients flow through it.
+    """
+
+    def __init__(self, selected_indices: Sequence[int], weights: Union[str, Dict[str, torch.Tensor], None] = None,
+                 seed: int = 0):
+        super().__init__()
+        if not isinstance(selected_indices, list):
+            raise ValueError(f"\n Selected indices should be provided as a list of layer indices,"
+                             f" you pass in {selected_indices}")
+        layout = vgg19_layers()
+        if any(idx >= len(layout) or idx < 0 for idx in selected_indices):
+            raise ValueError(f"\n Invalid layer index provided, the len of the model is {len(layout)}")
+        self.selected = sorted(set(int(i) for i in selected_indices))
+        self.last = max(self.selected)
+        self.layout = layout[: self.last + 1]
+        sd = self._load(weights)
+        g = torch.Generator().manual_seed(seed)
+        self.convs = nn.ModuleDict()
+        for idx, (kind, cin, cout) in enumerate(self.layout):
+            if kind != "conv":
+                continue
+            conv = nn.Conv2d(cin, cout, 3, padding=1)
+            if sd is not None:
+                v, b = sd[f"{idx}.weight"].float(), sd[f"{idx}.bias"].float()
+            else:
+                v = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cin * 9))
+                b = torch.zeros(cout)
+            # weight_norm(dim=0) with g initialised to ||v|| (trainer.py:179-181): w = g * v / ||v||
+            norm = v.reshape(cout, -1).norm(dim=1).view(-1, 1, 1, 1)
+            with torch.no_grad():
+                conv.weight.copy_(v * (norm / norm))
+                conv.bias.copy_(b)
+            self.convs[str(idx)] = conv
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self._packed = _PackedWeightCache()
+
+    @staticmethod
+    def _load(weights):
+        if weights is None:
+            warnings.warn("VGG19FeatureExtractor: no ImageNet weights given (torchvision's IMAGENET1K_V1 is a "
+                          "download); using a seeded random initialisation")
+            return None
+        sd = weights if isinstance(weights, dict) else torch.load(weights, map_location="cpu", weights_only=True)
+        # accept torchvision's full-model keys ("features.0.weight") or bare ones ("0.weight")
+        return {k[len("features."):] if k.startswith("features.") else k: v for k, v in sd.items()}
+
+    def forward(self, x) -> "OrderedDict[str, torch.Tensor]":
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        idx = 0
+        n = len(self.layout)
+        while idx < n:
+            kind = self.layout[idx][0]
+            if kind == "conv":
+                fuse_relu = idx + 1 < n          # the in-place ReLU that follows exists in the truncated model
+                conv = self.convs[str(idx)]
+                x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=False,
+                                  pad_mode=ops.PAD_ZERO, relu=fuse_relu)
+                if idx in self.selected:
+                    out[str(idx)] = x            # post-ReLU unless this conv is the last layer
+                if fuse_relu:
+                    if idx + 1 in self.selected:
+                        out[str(idx + 1)] = x
+                    idx += 1
+            elif kind == "pool":
+                x = maxpool2x2_apply(x, ceil_mode=False)
+                if idx in self.selected:
+                    out[str(idx)] = x
+            else:  # a ReLU not preceded by a conv cannot occur in VGG19
+                raise RuntimeError("unexpected layer order")
+            idx += 1
+        return OrderedDict((str(i), out[str(i)]) for i in self.selected)
+
+
+def get_feature_extractor(selected_indices, vgg_model_type: str = "19", device="cpu", weights=None):
+    """Signature of Trainer.get_feature_extractor (trainer.py:166); only "19" is ever used there."""
+    if vgg_model_type != "19":
+        raise ValueError("only the VGG19 loss network of the reference's build_model is implemented")
+    return VGG19FeatureExtractor(selected_indices, weights=weights).to(device)

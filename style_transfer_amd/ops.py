@@ -181,6 +181,21 @@ def conv1x1_3to3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) ->
     return y
 
 
+def normalize(x: torch.Tensor, mean, std) -> torch.Tensor:
+    """transforms.Normalize(mean, std) (trainer.py:299); mean=None gives x / std (its backward)."""
+    import ctypes
+    lib = _lib.load()
+    n, c, h, w = (int(v) for v in x.shape)
+    y = torch.empty_like(x)
+    arr = ctypes.c_float * c
+    m = arr(*[float(v) for v in mean]) if mean is not None else None
+    s = arr(*[float(v) for v in std])
+    _lib.check(lib.st_normalize_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(y, "y"), n, c, h * w,
+                                    ctypes.cast(m, ctypes.c_void_p) if m is not None else None,
+                                    ctypes.cast(s, ctypes.c_void_p), _lib.stream_ptr()), "st_normalize_fwd")
+    return y
+
+
 def maxpool2x2(x: torch.Tensor, ceil_mode: bool) -> torch.Tensor:
     """MaxPool2d((2,2),(2,2),(0,0),ceil_mode) (generator.py:53,60,73) / floor (torchvision vgg19)."""
     lib = _lib.load()

@@ -144,3 +144,31 @@ def test_tv_known_answer(golden_dir):
     assert float(TVLoss()(img.cuda())) == pytest.approx(float(kat["tv"]), rel=1e-5)     # 66.6369...
     one_row = torch.rand(1, 3, 1, 9, generator=torch.Generator().manual_seed(1))
     assert float(TVLoss()(one_row.cuda())) == pytest.approx(float(R.tv_loss(one_row)), rel=1e-5)
+
+
+def test_loss_vgg_features_and_grad():
+    """VGG19 feature extractor (parity unpinned by the reference: torchvision absent) vs the oracle's
+    restatement, including the in-place-ReLU capture rule and the data gradient through conv+pool."""
+    from style_transfer_amd.loss_network import Normalize, VGG19FeatureExtractor
+    sd = R.make_loss_vgg_state(seed=2, upto=25)
+    idxs = [2, 7, 14, 19, 25]
+    ext = VGG19FeatureExtractor(idxs, weights=sd).cuda()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 40, 36, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = R.loss_vgg_features(R.normalize(xr), sd, idxs)
+    xg = x.cuda().requires_grad_(True)
+    got = list(ext(Normalize()(xg)).values())
+    assert len(got) == len(ref) == 5
+    loss_ref = sum((f * f).mean() for f in ref)
+    loss_ref.backward()
+    loss = sum((f * f).mean() for f in got)
+    loss.backward()
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-4
+    assert float(got[-1].min()) < 0 and float(got[0].min()) >= 0     # last kept conv is pre-ReLU
+    assert rel_err(xg.grad, xr.grad) < 1e-3
+    # single index = content extractor [21]
+    ext21 = VGG19FeatureExtractor([21], weights=R.make_loss_vgg_state(seed=2, upto=21)).cuda()
+    f21 = list(ext21(x.cuda()).values())[0]
+    assert rel_err(f21, R.loss_vgg_features(x, R.make_loss_vgg_state(seed=2, upto=21), [21])[0]) < 1e-4
