@@ -173,6 +173,33 @@ int st_meanstd_loss_bwd(const float* x, const float* mean_a, const float* std_a,
                         const float* std_b, const float* gout, float scale, float* dx, int planes,
                         int hw, int accumulate, st_stream_t stream);
 
+/* ---- RGB-uv histogram (RGBuvHistBlock.forward, losses.py:169-322; 'interpolation' resizing,
+ * green_only = False, h = 64) and the Hellinger distance of HistLoss (losses.py:338-347) -------
+ *   x:      [n][c>=3][h][w] (first three channels are used, losses.py:192-193)
+ *   hist:   [n][3][64][64] normalised (each image sums to 1); totals: [n] un-normalised sums
+ *   bins_host: HOST array of nbins (= 64) float64 bin centres, np.linspace(lo, hi, 64)
+ *   method: ST_HIST_*; sigma as in losses.py:124; insz: resize threshold/size (HistLoss: 128)
+ * In ST_HIST_THRESHOLDING with intensity_scale = 0 the un-normalised bins are exact integer
+ * counts (no atomics, exact fp32 sums).  workspace: st_rgbuv_hist_workspace_bytes(). */
+size_t st_rgbuv_hist_workspace_bytes(int n, int h, int w, int insz);
+int st_rgbuv_hist_fwd(const float* x, float* hist, float* totals, float* workspace, int n, int c,
+                      int h, int w, int insz, int method, float sigma, const double* bins_host,
+                      int nbins, int intensity_scale, st_stream_t stream);
+/* dx (+)= gout*scale * d<ghist, hist>/dx, through normalisation, kernel weights, log-chroma,
+ * intensity, bilinear resize and clamp.  hist/totals: the forward outputs. */
+int st_rgbuv_hist_bwd(const float* x, const float* hist, const float* totals, const float* ghist,
+                      const float* gout, float scale, float* dx, float* workspace, int n, int c,
+                      int h, int w, int insz, int method, float sigma, const double* bins_host,
+                      int nbins, int intensity_scale, int accumulate, st_stream_t stream);
+
+/* out[0] = sum_k (sqrt(h_target[k]) - sqrt(h_input[k]))^2 over the whole batch (the quantity under
+ * the outer sqrt of losses.py:342-344; data-parallel training all-reduces exactly this scalar).
+ * bwd: dh_input = gq*scale * d out / d h_input.  workspace >= st_reduce_workspace_bytes(). */
+int st_hellinger_sq_fwd(const float* h_target, const float* h_input, long long n, float* workspace,
+                        float* out, st_stream_t stream);
+int st_hellinger_sq_bwd(const float* h_target, const float* h_input, const float* gq, float scale,
+                        float* dh_input, long long n, st_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

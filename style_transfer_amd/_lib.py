@@ -45,6 +45,14 @@ SIGNATURES = {
     "st_meanstd_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "st_meanstd_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                     c_int, c_int, c_int, c_void_p]),
+    "st_rgbuv_hist_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "st_rgbuv_hist_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_float, c_void_p, c_int, c_int, c_void_p]),
+    "st_rgbuv_hist_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int,
+                                  c_void_p]),
+    "st_hellinger_sq_fwd": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
+    "st_hellinger_sq_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong, c_void_p]),
     "st_meanstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
 }
 

@@ -138,3 +138,135 @@ class TVLoss(nn.Module):
     @staticmethod
     def _tensor_size(t):
         return t.size()[1] * t.size()[2] * t.size()[3]
+
+
+# --------------------------------------------------------------------------------------------
+EPS = 1e-6   # losses.py:119
+_HIST_METHODS = {"inverse-quadratic": 0, "RBF": 1, "thresholding": 2}
+
+
+class _RGBuvHistFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, insz, method, sigma, bins, intensity_scale):
+        import ctypes
+        lib = _lib.load()
+        n, c, h, w = (int(v) for v in x.shape)
+        hist = torch.empty((n, 3, 64, 64), dtype=torch.float32, device=x.device)
+        totals = torch.empty(n, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.st_rgbuv_hist_workspace_bytes(n, h, w, insz) // 4, dtype=torch.float32, device=x.device)
+        barr = (ctypes.c_double * len(bins))(*[float(b) for b in bins])
+        _lib.check(lib.st_rgbuv_hist_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(hist, "hist"), _lib.dev_ptr(totals, "totals"),
+                                         _lib.dev_ptr(ws, "workspace"), n, c, h, w, insz, method, float(sigma),
+                                         ctypes.cast(barr, ctypes.c_void_p), len(bins), int(intensity_scale),
+                                         _lib.stream_ptr()), "st_rgbuv_hist_fwd")
+        ctx.cfg = (insz, method, sigma, tuple(bins), intensity_scale)
+        ctx.save_for_backward(x, hist, totals)
+        return hist
+
+    @staticmethod
+    def backward(ctx, ghist):
+        import ctypes
+        x, hist, totals = ctx.saved_tensors
+        insz, method, sigma, bins, intensity_scale = ctx.cfg
+        lib = _lib.load()
+        n, c, h, w = (int(v) for v in x.shape)
+        dx = torch.empty_like(x)
+        ws = torch.empty(lib.st_rgbuv_hist_workspace_bytes(n, h, w, insz) // 4, dtype=torch.float32, device=x.device)
+        barr = (ctypes.c_double * len(bins))(*bins)
+        ghist = ghist.contiguous()
+        _lib.check(lib.st_rgbuv_hist_bwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(hist, "hist"), _lib.dev_ptr(totals, "totals"),
+                                         _lib.dev_ptr(ghist, "ghist"), None, 1.0, _lib.dev_ptr(dx, "dx"),
+                                         _lib.dev_ptr(ws, "workspace"), n, c, h, w, insz, method, float(sigma),
+                                         ctypes.cast(barr, ctypes.c_void_p), len(bins), int(intensity_scale), 0,
+                                         _lib.stream_ptr()), "st_rgbuv_hist_bwd")
+        return dx, None, None, None, None, None
+
+
+class RGBuvHistBlock(nn.Module):
+    """losses.py:122-322.  Supported on the HIP path: h=64, resizing='interpolation',
+    green_only=False (the configuration HistLoss builds, losses.py:333-336); other settings raise."""
+
+    def __init__(self, h=64, insz=150, resizing='interpolation', method='inverse-quadratic', sigma=0.02,
+                 intensity_scale=True, hist_boundary=None, green_only=False, device='cuda'):
+        super().__init__()
+        self.h = h
+        self.insz = insz
+        self.device = device
+        self.resizing = resizing
+        self.method = method
+        self.intensity_scale = intensity_scale
+        self.green_only = green_only
+        if hist_boundary is None:
+            hist_boundary = [-3, 3]
+        hist_boundary.sort()
+        self.hist_boundary = hist_boundary
+        if self.method == 'thresholding':
+            self.eps = (abs(hist_boundary[0]) + abs(hist_boundary[1])) / h
+        self.sigma = sigma
+        if h != 64 or green_only or resizing != 'interpolation':
+            raise NotImplementedError("HIP RGBuvHistBlock supports h=64, green_only=False, resizing='interpolation'")
+        if method not in _HIST_METHODS:
+            raise Exception(f'Wrong kernel method. It should be either thresholding, RBF,'
+                            f' inverse-quadratic. But the given value is {self.method}.')
+        # float64 bin centres exactly as the reference builds them (losses.py:211-213)
+        self._bins = [float(v) for v in np.linspace(self.hist_boundary[0], self.hist_boundary[1], num=self.h)]
+
+    def forward(self, x):
+        return _RGBuvHistFunction.apply(x.contiguous(), int(self.insz), _HIST_METHODS[self.method], float(self.sigma),
+                                        self._bins, bool(self.intensity_scale))
+
+
+class _HellingerSqFunction(torch.autograd.Function):
+    """q = sum (sqrt(target_hist) - sqrt(input_hist))^2; gradient to input_hist only."""
+
+    @staticmethod
+    def forward(ctx, target_hist, input_hist):
+        lib = _lib.load()
+        out = torch.empty(1, dtype=torch.float32, device=input_hist.device)
+        _lib.check(lib.st_hellinger_sq_fwd(_lib.dev_ptr(target_hist, "target_hist"), _lib.dev_ptr(input_hist, "input_hist"),
+                                           input_hist.numel(), _lib.dev_ptr(_workspace(input_hist.device), "ws"),
+                                           _lib.dev_ptr(out, "out"), _lib.stream_ptr()), "st_hellinger_sq_fwd")
+        ctx.save_for_backward(target_hist, input_hist)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gq):
+        target_hist, input_hist = ctx.saved_tensors
+        lib = _lib.load()
+        dh = torch.empty_like(input_hist)
+        gq = gq.contiguous().reshape(1)
+        _lib.check(lib.st_hellinger_sq_bwd(_lib.dev_ptr(target_hist, "target_hist"), _lib.dev_ptr(input_hist, "input_hist"),
+                                           _lib.dev_ptr(gq, "gq"), 1.0, _lib.dev_ptr(dh, "dh"), input_hist.numel(),
+                                           _lib.stream_ptr()), "st_hellinger_sq_bwd")
+        return None, dh
+
+
+def hellinger_sq(target_hist, input_hist):
+    return _HellingerSqFunction.apply(target_hist.detach().contiguous(), input_hist.contiguous())
+
+
+class HistLoss(nn.Module):
+    """losses.py:325-347.  ``reduce_q`` (optional) is applied to the scalar under the outer sqrt --
+    data-parallel training passes an all-reduce there so the loss equals the single-GPU
+    large-batch value (the sqrt is OUTSIDE the batch sum); ``global_batch`` then replaces B."""
+
+    def __init__(self, intensity_scale=True, histogram_size=64, max_input_size=128, hist_boundary=[-3, 3],
+                 method='inverse-quadratic'):
+        super().__init__()
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.histogram_block = RGBuvHistBlock(insz=max_input_size, h=histogram_size, intensity_scale=intensity_scale,
+                                              method=method, hist_boundary=list(hist_boundary), device=device)
+
+    def from_hists(self, input_hist, target_hist, reduce_q=None, global_batch=None):
+        q = hellinger_sq(target_hist, input_hist)
+        if reduce_q is not None:
+            q = reduce_q(q)
+        batch = input_hist.shape[0] if global_batch is None else global_batch
+        histogram_loss = (1 / np.sqrt(2.0) * (torch.sqrt(q)) / batch)
+        return histogram_loss * 100
+
+    def forward(self, input, target, reduce_q=None, global_batch=None):
+        input_hist = self.histogram_block(input)
+        with torch.no_grad():
+            target_hist = self.histogram_block(target)
+        return self.from_hists(input_hist, target_hist, reduce_q, global_batch)

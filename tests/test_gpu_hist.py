@@ -1,0 +1,113 @@
+"""GPU parity of the RGB-uv histogram / HistLoss kernels against reference-generated golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("method", ["inverse-quadratic", "RBF", "thresholding"])
+@pytest.mark.parametrize("iscale", [True, False])
+def test_hist_block_golden(golden_dir, method, iscale):
+    from style_transfer_amd.losses import RGBuvHistBlock
+    g = np.load(os.path.join(golden_dir, "hist.npz"))
+    blk = RGBuvHistBlock(insz=128, h=64, intensity_scale=iscale, method=method, hist_boundary=[-3, 3])
+    tag = f"{method}_{int(iscale)}"
+    for which in ("small", "big"):
+        h = blk(torch.from_numpy(g[which]).cuda())
+        ref = torch.from_numpy(g[f"hist_{which}_{tag}"])
+        assert h.shape == ref.shape
+        np.testing.assert_allclose(h.sum(dim=(1, 2, 3)).cpu(), ref.sum(dim=(1, 2, 3)), rtol=1e-5)
+        if method == "thresholding":
+            # hard bins: a pixel whose log-chroma sits within an ulp of a bin edge may flip between
+            # torch-CPU log and device logf; everything else is exact
+            # (a flip moves one pixel's weight, <= sqrt(3)/total of the normalised mass)
+            n_px = 24 * 20 if which == "small" else 128 * 128
+            big_diff = int(((h.cpu() - ref).abs() > 0.25 / n_px).sum())
+            assert big_diff <= 8, f"{big_diff} bins differ by more than a quarter pixel"
+            assert rel_err(h, ref) < 2e-2
+        else:
+            assert rel_err(h, ref) < 1e-4
+
+
+def test_hist_exact_integer_counts():
+    """Bit-exact bin COUNTS (thresholding, intensity_scale=False) on pixels whose log-chroma is
+    provably away from every bin edge, so the result does not depend on the last ulp of log()."""
+    from style_transfer_amd.losses import RGBuvHistBlock
+    g = torch.Generator().manual_seed(123)
+    cand = torch.rand(400000, 3, generator=g, dtype=torch.float64) * 0.98 + 0.01
+    logc = torch.log(cand + 1e-6)
+    bins = torch.tensor(np.linspace(-3, 3, 64))
+    keep = torch.ones(cand.shape[0], dtype=torch.bool)
+    thr = 6.0 / 64 / 2
+    for a in range(3):
+        for b in range(3):
+            if a != b:
+                d = (logc[:, a] - logc[:, b]).unsqueeze(1) - bins.unsqueeze(0)
+                keep &= ((d.abs() - thr).abs() > 1e-4).all(dim=1)
+    px = cand[keep][: 2 * 100 * 100].float()
+    assert px.shape[0] == 20000
+    img = px.t().reshape(3, 2, 100, 100).permute(1, 0, 2, 3).contiguous()      # [2,3,100,100] (<= insz: no resize)
+    ref = R.rgbuv_hist(img, method="thresholding", intensity_scale=False)
+    blk = RGBuvHistBlock(insz=128, h=64, intensity_scale=False, method="thresholding", hist_boundary=[-3, 3])
+    h = blk(img.cuda()).cpu()
+    # un-normalise with the exact integer total of an independent direct count
+    raw_ref = _raw_counts(img)
+    tot = raw_ref.sum(dim=(1, 2, 3), keepdim=True)
+    assert float(tot.min()) > 1000
+    raw_hip = torch.round(h.double() * (tot.double() + 1e-6))
+    assert torch.equal(raw_hip, raw_ref.double())     # bit-exact integer bin counts
+    assert torch.equal(h, ref)                        # and identical normalised fp32 values vs the oracle
+
+
+def _raw_counts(img):
+    """Integer bin counts by direct counting (independent of both implementations' float paths)."""
+    logc = torch.log(img.clamp(0, 1) + 1e-6)             # fp32, as both implementations do
+    bins = torch.tensor(np.linspace(-3, 3, 64))
+    thr = 6.0 / 64 / 2
+    out = torch.zeros(img.shape[0], 3, 64, 64)
+    for l in range(img.shape[0]):
+        L = logc[l].reshape(3, -1)
+        for ch, (o1, o2) in enumerate(((1, 2), (0, 2), (0, 1))):
+            u = (L[ch] - L[o1]).double().unsqueeze(1)
+            v = (L[ch] - L[o2]).double().unsqueeze(1)
+            mu = ((u - bins).abs() <= thr).float()
+            mv = ((v - bins).abs() <= thr).float()
+            out[l, ch] = mu.t() @ mv
+    return out
+
+
+def test_hist_loss_golden(golden_dir):
+    from style_transfer_amd.losses import HistLoss
+    g = np.load(os.path.join(golden_dir, "hist.npz"))
+    hl = HistLoss()
+    x = torch.from_numpy(g["small"]).cuda().requires_grad_(True)
+    v = hl(x, torch.from_numpy(g["tgt_small"]).cuda())
+    v.backward()
+    assert float(v) == pytest.approx(float(g["histloss"]), rel=1e-4)
+    assert rel_err(x.grad, torch.from_numpy(g["histloss_dsmall"])) < 2e-3
+    xb = torch.from_numpy(g["big"]).cuda().requires_grad_(True)
+    tgt = torch.rand(2, 3, 150, 141, generator=torch.Generator().manual_seed(41)).cuda()
+    v = hl(xb, tgt)
+    v.backward()
+    assert float(v) == pytest.approx(float(g["histloss_big"]), rel=1e-4)
+    assert rel_err(xb.grad, torch.from_numpy(g["histloss_dbig"])) < 2e-3
+
+
+def test_hist_loss_known_answer(golden_dir):
+    from style_transfer_amd.losses import HistLoss
+    kat = np.load(os.path.join(golden_dir, "kat.npz"))
+    torch.manual_seed(0)
+    img = torch.rand(8, 3, 256, 256)
+    tgt = torch.rand(8, 3, 256, 256)
+    v = HistLoss()(img.cuda(), tgt.cuda())
+    assert float(v) == pytest.approx(float(kat["histloss"]), rel=1e-4)       # 2.91424...
