@@ -200,6 +200,17 @@ int st_hellinger_sq_fwd(const float* h_target, const float* h_input, long long n
 int st_hellinger_sq_bwd(const float* h_target, const float* h_input, const float* gq, float scale,
                         float* dh_input, long long n, st_stream_t stream);
 
+/* ---- un-normalised covariance of VincentStyleLoss.calc_2_moments (losses.py:49-54) -----------
+ * x: [b][c][n] (n = H*W), mean: [b][c] (st_meanstd_fwd), cov: [b][c][c] = (x-mean)(x-mean)^T.
+ * MFMA GEMM over pixels, split-K slabs in `workspace` (st_cov_workspace_bytes), fixed-order sum.
+ * bwd: dx = (gcov + gcov^T)(x - mean) + gmean / n   (gmean [b][c] nullable).
+ * The eigendecompositions of l2wass_dist (losses.py:67-81) stay on torch.linalg.eigh. */
+size_t st_cov_workspace_bytes(int b, int c, int n);
+int st_cov_fwd(const float* x, const float* mean, float* cov, float* workspace, int b, int c, int n,
+               st_stream_t stream);
+int st_cov_bwd(const float* x, const float* mean, const float* gcov, const float* gmean, float* dx,
+               int b, int c, int n, st_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ SIGNATURES = {
                                   c_void_p]),
     "st_hellinger_sq_fwd": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     "st_hellinger_sq_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong, c_void_p]),
+    "st_cov_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "st_cov_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "st_cov_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "st_meanstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
 }
 

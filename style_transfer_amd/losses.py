@@ -270,3 +270,78 @@ class HistLoss(nn.Module):
         with torch.no_grad():
             target_hist = self.histogram_block(target)
         return self.from_hists(input_hist, target_hist, reduce_q, global_batch)
+
+
+# --------------------------------------------------------------------------------------------
+class _MomentsFunction(torch.autograd.Function):
+    """calc_2_moments: (mu [b,c,1], cov [b,c,c] un-normalised), MFMA covariance both ways."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        b, c, h, w = (int(v) for v in x.shape)
+        n = h * w
+        mean, _ = ops.mean_std(x, 1e-5)
+        mean = mean.reshape(b, c)
+        cov = torch.empty((b, c, c), dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.st_cov_workspace_bytes(b, c, n) // 4, dtype=torch.float32, device=x.device)
+        ev = None
+        if ops.KERNEL_TIMER.enabled:
+            ev = ops.KERNEL_TIMER.record("cov_fwd_kernel", 2.0 * b * c * c * n, 4.0 * x.numel())
+        _lib.check(lib.st_cov_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(mean, "mean"), _lib.dev_ptr(cov, "cov"),
+                                  _lib.dev_ptr(ws, "workspace"), b, c, n, _lib.stream_ptr()), "st_cov_fwd")
+        if ev is not None:
+            ev.record()
+        ctx.save_for_backward(x, mean)
+        return mean.reshape(b, c, 1), cov
+
+    @staticmethod
+    def backward(ctx, gmu, gcov):
+        x, mean = ctx.saved_tensors
+        lib = _lib.load()
+        b, c, h, w = (int(v) for v in x.shape)
+        dx = torch.empty_like(x)
+        gcov = gcov.contiguous()
+        gmu = gmu.contiguous().reshape(b, c) if gmu is not None else None
+        _lib.check(lib.st_cov_bwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(mean, "mean"), _lib.dev_ptr(gcov, "gcov"),
+                                  _lib.dev_ptr(gmu, "gmean") if gmu is not None else None, _lib.dev_ptr(dx, "dx"),
+                                  b, c, h * w, _lib.stream_ptr()), "st_cov_bwd")
+        return dx
+
+
+class VincentStyleLoss(nn.Module):
+    """losses.py:42-90.  The covariance (the O(C^2 HW) "Gram" term) and its gradient are MFMA
+    kernels; the C x C eigendecompositions and products of ``l2wass_dist`` stay on
+    ``torch.linalg.eigh`` / ``torch.matmul`` (rocSOLVER / rocBLAS), as SURVEY.md K7b records."""
+
+    def __init__(self, scale_factor=1e-5):
+        super().__init__()
+        warnings.warn("\n Using VincentStyleLoss might me slow!")
+        self.scale_factor = scale_factor
+
+    @staticmethod
+    def calc_2_moments(x):
+        return _MomentsFunction.apply(x.contiguous())
+
+    @staticmethod
+    def matrix_diag(diagonal):
+        return torch.diag_embed(diagonal)
+
+    def l2wass_dist(self, mean_stl, cov_stl, mean_synth, cov_synth):
+        eigvals, eigvects = torch.linalg.eigh(cov_stl)
+        eigroot_mat = self.matrix_diag(torch.sqrt(eigvals.clip(0)))
+        root_cov_stl = torch.matmul(torch.matmul(eigvects, eigroot_mat), torch.transpose(eigvects, -1, -2))
+        tr_cov_stl = torch.sum(eigvals.clip(0), dim=1, keepdim=True)
+        tr_cov_synth = torch.sum(torch.linalg.eigvalsh(cov_synth).clip(0), dim=1, keepdim=True)
+        mean_diff_squared = torch.mean((mean_synth - mean_stl) ** 2)
+        cov_prod = torch.matmul(torch.matmul(root_cov_stl, cov_synth), root_cov_stl)
+        var_overlap = torch.sum(torch.sqrt(torch.linalg.eigvalsh(cov_prod).clip(0.1)), dim=1, keepdim=True)
+        dist = mean_diff_squared + tr_cov_stl + tr_cov_synth - 2 * var_overlap
+        return dist
+
+    def forward(self, input_f, target_f):
+        mean_synth, cov_synth = self.calc_2_moments(input_f)
+        with torch.no_grad():
+            mean_stl, cov_stl = self.calc_2_moments(target_f)
+        loss = self.l2wass_dist(mean_stl, cov_stl, mean_synth, cov_synth)
+        return loss.mean() * self.scale_factor
