@@ -114,6 +114,12 @@ int st_conv1x1_3to3_fwd(const float* x, const float* w /*[3][3]*/, const float* 
 int st_normalize_fwd(const float* x, float* y, int n, int c, int hw, const float* mean_host,
                      const float* std_host, st_stream_t stream);
 
+/* ---- stand-alone nn.ReLU (torchvision vgg19 ReLU(inplace=True)); the conv kernels fuse it, this
+ * exists for the one place a pre-ReLU feature has to survive (shared loss-VGG pass).
+ * bwd: dx = dy where y > 0 (y = the ReLU output). */
+int st_relu_fwd(const float* x, float* y, long long n, st_stream_t stream);
+int st_relu_bwd(const float* y, const float* dy, float* dx, long long n, st_stream_t stream);
+
 /* ---- 2x2 stride-2 max pool (generator.py:53,60,73; torchvision vgg19 'M') ------------- */
 int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, int ceil_mode,
                       st_stream_t stream);

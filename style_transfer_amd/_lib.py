@@ -31,6 +31,8 @@ SIGNATURES = {
     "st_maxpool2x2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_sympad_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "st_normalize_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "st_relu_fwd": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
+    "st_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
     "st_conv1x1_3to3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "st_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_adain_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,

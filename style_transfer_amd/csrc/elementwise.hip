@@ -199,3 +199,29 @@ extern "C" int st_normalize_fwd(const float* x, float* y, int n, int c, int hw, 
                      (long long)hw, total, a);
   return st::check_launch("st_normalize_fwd");
 }
+
+// ---- stand-alone ReLU (only where a pre-ReLU feature must be kept: shared loss-VGG pass) --------
+namespace {
+__global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                  long long n) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    y[e] = fmaxf(x[e], 0.f);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, long long n) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    dx[e] = y[e] > 0.f ? dy[e] : 0.f;
+}
+}  // namespace
+
+extern "C" int st_relu_fwd(const float* x, float* y, long long n, st_stream_t stream) {
+  ST_REQUIRE(x && y && n > 0, "st_relu_fwd: bad arguments");
+  hipLaunchKernelGGL(relu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return st::check_launch("st_relu_fwd");
+}
+
+extern "C" int st_relu_bwd(const float* y, const float* dy, float* dx, long long n, st_stream_t stream) {
+  ST_REQUIRE(y && dy && dx && n > 0, "st_relu_bwd: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n);
+  return st::check_launch("st_relu_bwd");
+}

@@ -52,6 +52,28 @@ class _NormalizeFunction(torch.autograd.Function):
         return ops.normalize(g.contiguous(), None, ctx.std), None, None
 
 
+class _ReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        _lib.check(lib.st_relu_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(y, "y"), x.numel(), _lib.stream_ptr()), "st_relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        (y,) = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(lib.st_relu_bwd(_lib.dev_ptr(y, "y"), _lib.dev_ptr(dy, "dy"), _lib.dev_ptr(dx, "dx"), y.numel(),
+                                   _lib.stream_ptr()), "st_relu_bwd")
+        return dx
+
+
 class Normalize(nn.Module):
     """transforms.Normalize(mean, std) for batched NCHW tensors (trainer.py:299)."""
 
@@ -117,6 +139,45 @@ class VGG19FeatureExtractor(nn.Module):
         sd = weights if isinstance(weights, dict) else torch.load(weights, map_location="cpu", weights_only=True)
         # accept torchvision's full-model keys ("features.0.weight") or bare ones ("0.weight")
         return {k[len("features."):] if k.startswith("features.") else k: v for k, v in sd.items()}
+
+    def forward_multi(self, x, index_sets: Sequence[Sequence[int]]) -> List[List[torch.Tensor]]:
+        """One pass that serves several extractors at once (the reference runs the content and the
+        style extractor separately on the same decoded image, trainer.py:447,454).  Each set gets
+        exactly what ITS extractor would return: a conv index that is the last layer of its own
+        truncated model is captured pre-ReLU, every other captured conv post-ReLU."""
+        sets = [sorted(set(int(i) for i in s)) for s in index_sets]
+        last_all = max(max(s) for s in sets)
+        assert last_all <= self.last, "extractor was built for a shallower network"
+        need_pre = {max(s) for s in sets if self.layout[max(s)][0] == "conv"}
+        pre: Dict[int, torch.Tensor] = {}
+        post: Dict[int, torch.Tensor] = {}
+        idx = 0
+        while idx <= last_all:
+            kind = self.layout[idx][0]
+            if kind == "conv":
+                conv = self.convs[str(idx)]
+                cont = idx + 1 <= last_all       # some extractor continues past this conv
+                if idx in need_pre:
+                    x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=False,
+                                      pad_mode=ops.PAD_ZERO, relu=False)
+                    pre[idx] = x
+                    if cont:
+                        x = _ReLUFunction.apply(x)
+                        post[idx] = post[idx + 1] = x
+                        idx += 1
+                else:
+                    x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=False,
+                                      pad_mode=ops.PAD_ZERO, relu=True)
+                    post[idx] = post[idx + 1] = x
+                    idx += 1
+            else:
+                x = maxpool2x2_apply(x, ceil_mode=False)
+                post[idx] = x
+            idx += 1
+        res = []
+        for s in sets:
+            res.append([pre[i] if (i == max(s) and i in pre) else post[i] for i in s])
+        return res
 
     def forward(self, x) -> "OrderedDict[str, torch.Tensor]":
         out: "OrderedDict[str, torch.Tensor]" = OrderedDict()

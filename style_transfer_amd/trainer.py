@@ -1,0 +1,426 @@
+"""Training step, loss mix, checkpoint save/resume and data-parallel glue with the reference's
+``Trainer`` surface (src/models/trainer.py), every tensor op of the step on HIP kernels.
+
+Differences that do not change results: the encoder and the loss network are
+frozen instead of accumulating never-read gradients; the decoded image goes through the loss
+VGG once for both extractors; the stylised histogram is computed once for both Hellinger terms;
+per-step scalars stay on the device and are read once per epoch.
+
+Data parallel (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL over xGMI): the
+batch is sharded by rank, one flat fp32 bucket (decoder grads + the two AdaIN eps grads, 14.02 MB)
+is all-reduced per step, the Hellinger scalar under the outer sqrt is all-reduced in the forward so
+the histogram loss equals the single-GPU large-batch value, the AdaIN gradient clamp is applied
+after the reduction, and only rank 0 writes checkpoints.
+"""
+from __future__ import annotations
+
+import datetime
+import math
+import os
+import warnings
+from argparse import Namespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+from torch.optim import lr_scheduler
+
+from .generator import Decoder, Encoder
+from .loss_network import IMAGENET_MEAN, IMAGENET_STD, Normalize, VGG19FeatureExtractor
+from .losses import AdaINContentLoss, AdaINStyleLoss, HistLoss, TVLoss, VincentStyleLoss
+from .transformer import AdaIN
+
+PRJ_NAME = "Style_transfer"   # trainer.py:36
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel helpers
+# ---------------------------------------------------------------------------------------------
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+class _AllReduceSumScaledGrad(torch.autograd.Function):
+    """Q = sum over ranks of q (forward); d q_local = world_size * dQ (backward).
+
+    With the per-rank gradients averaged afterwards (mean all-reduce of the bucket) the scaled
+    backward makes the histogram term's gradient equal d L_global / d theta exactly
+    (the sqrt of HistLoss sits outside the batch sum)."""
+
+    @staticmethod
+    def forward(ctx, q):
+        dist = _dist()
+        out = q.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        ctx.world = dist.get_world_size()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.world
+
+
+def allreduce_q(q):
+    return _AllReduceSumScaledGrad.apply(q) if _dist() is not None else q
+
+
+class GradBucket:
+    """One flat fp32 buffer for every trainable gradient; a single RCCL all-reduce per step."""
+
+    def __init__(self, params: List[nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat: Optional[torch.Tensor] = None
+
+    def reduce_mean(self):
+        dist = _dist()
+        if dist is None or dist.get_world_size() == 1:
+            return
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(dist.get_world_size())
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = self.flat[off:off + n].reshape(p.shape).clone()
+            else:
+                p.grad.copy_(self.flat[off:off + n].reshape(p.shape))
+            off += n
+
+
+# ---------------------------------------------------------------------------------------------
+# the step engine (hot path)
+# ---------------------------------------------------------------------------------------------
+class StyleTransferStep:
+    """Forward half of the train-step body (trainer.py:426-464) + compute_loss (:246-279)."""
+
+    def __init__(self, encoder: Encoder, decoder: Decoder, transformer: AdaIN, loss_vgg: VGG19FeatureExtractor,
+                 content_layers_idx: List[int], style_layers_idx: List[int], alpha: float, beta: float, gamma: float,
+                 delta: float, use_VincentStyleLoss: bool = False):
+        self.encoder, self.decoder, self.transformer, self.loss_vgg = encoder, decoder, transformer, loss_vgg
+        self.content_layers_idx, self.style_layers_idx = list(content_layers_idx), list(style_layers_idx)
+        self.alpha, self.beta, self.gamma, self.delta = alpha, beta, gamma, delta
+        self.variation_loss = TVLoss()
+        if use_VincentStyleLoss:
+            self.style_loss = VincentStyleLoss()
+        else:
+            self.style_loss = AdaINStyleLoss()
+        self.content_loss = AdaINContentLoss()
+        self.hist_loss = HistLoss()
+        self.norm = Normalize(IMAGENET_MEAN, IMAGENET_STD)
+
+    def compute_loss(self, content_features, style_features, stylized_outputs, style_imgs, content_imgs,
+                     global_batch: Optional[int] = None):
+        """Trainer.compute_loss: *_features are lists of {"model_output", "orginal"} dicts."""
+        loss_content = sum(self.content_loss(f['model_output'], f['orginal']) for f in content_features)
+        loss_style = sum(self.style_loss(f['model_output'], f['orginal']) for f in style_features)
+        variation_loss = self.variation_loss(stylized_outputs)
+        blk = self.hist_loss.histogram_block
+        stylized_hist = blk(stylized_outputs)             # computed once, used by both terms
+        with torch.no_grad():
+            style_hist, content_hist = blk(style_imgs), blk(content_imgs)
+        histogram_loss_S = self.hist_loss.from_hists(stylized_hist, style_hist, allreduce_q, global_batch)
+        histogram_loss_C = self.hist_loss.from_hists(stylized_hist, content_hist, allreduce_q, global_batch)
+        histogram_loss = 0.4 * histogram_loss_S + 0.6 * histogram_loss_C
+        total_loss = self.alpha * loss_content + self.beta * loss_style + self.gamma * variation_loss \
+            + self.delta * histogram_loss
+        return loss_content, loss_style, variation_loss, histogram_loss, total_loss
+
+    def forward_losses(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, global_batch: Optional[int] = None):
+        with torch.no_grad():                              # frozen encoder: forward only
+            encode_Cfeatures = self.encoder(content_imgs)
+            encode_Sfeatures = self.encoder(style_imgs)
+        transformed_features = self.transformer(encode_Cfeatures, encode_Sfeatures, alpha=1.0)   # trainer.py:433-434
+        decode_imgs = self.decoder(transformed_features)
+        content_n, style_n = self.norm(content_imgs), self.norm(style_imgs)
+        decode_n = self.norm(decode_imgs)
+        with torch.no_grad():
+            org_content = self.loss_vgg.forward_multi(content_n, [self.content_layers_idx])[0]
+            org_style = self.loss_vgg.forward_multi(style_n, [self.style_layers_idx])[0]
+        gen_content, gen_style = self.loss_vgg.forward_multi(decode_n, [self.content_layers_idx, self.style_layers_idx])
+        # the reference indexes the getter's layer-ordered outputs by position (trainer.py:448-457)
+        content_features = [{"orginal": o, "model_output": g} for o, g in zip(org_content, gen_content)]
+        style_features = [{"orginal": o, "model_output": g} for o, g in zip(org_style, gen_style)]
+        return self.compute_loss(content_features, style_features, decode_n, style_n, content_n, global_batch)
+
+
+# ---------------------------------------------------------------------------------------------
+class Trainer:
+    """Constructor keywords, optimizer names, checkpoint layout and resume rules of the reference
+    Trainer (trainer.py:39-108, 201-232, 304-388, 607-655).  Extra keywords (all optional):
+    ``encoder_weights`` / ``decoder_weights`` / ``vgg_weights`` (paths or state dicts; the blobs
+    the reference hard-codes are not shipped), ``device``."""
+
+    def __init__(self, dataloaders, output_dir: str, num_train_epochs: int, per_device_batch_size: int,
+                 learning_rate: float, alpha: float, beta: float, gamma: float, seed: int = 42,
+                 do_eval_per_epoch: bool = True, plot_per_epoch: bool = False, save_best: bool = True,
+                 resume_from_checkpoint: str = None, vgg_model_type: str = '19',
+                 optim_name: dict = {'optim_name': 'adam'}, with_tracking: bool = False,
+                 log_weights_cpkt: bool = False, do_decoder_train: bool = False,
+                 use_pretrained_WCTDECODER: bool = False, delta: float = 2, eps: float = 1e-5,
+                 step_frequency: float = 0.5, gradient_threshold: float = None, config: Namespace = None,
+                 grayscale_content_transform: bool = False, use_VincentStyleLoss: bool = False,
+                 content_layers_idx: List[int] = [12, 16, 21], style_layers_idx: List[int] = [0, 5, 10, 19, 28],
+                 encoder_weights=None, decoder_weights=None, vgg_weights=None, device=None):
+        self.output_dir = output_dir
+        self.dataloaders = dataloaders.__call__() if callable(dataloaders) else dataloaders
+        self.per_device_batch_size = per_device_batch_size
+        self.alpha, self.beta, self.gamma, self.delta, self.eps = alpha, beta, gamma, delta, eps
+        self.vgg_model_type = vgg_model_type
+        self.learning_rate = learning_rate
+        self.content_layers_idx = list(content_layers_idx)
+        self.style_layers_idx = list(style_layers_idx)
+        self.num_train_epochs = num_train_epochs
+        self.step_frequency = step_frequency
+        self.optim_name = dict(optim_name)
+        self.gradient_threshold = gradient_threshold
+        self.do_decoder_train = do_decoder_train
+        self.use_pretrained_WCTDECODER = use_pretrained_WCTDECODER
+        self.grayscale_content_transform = grayscale_content_transform
+        self.use_VincentStyleLoss = use_VincentStyleLoss
+        self.with_tracking = with_tracking
+        self.log_weights_cpkt = log_weights_cpkt
+        self.plot_per_epoch = plot_per_epoch
+        self.save_best = save_best
+        self.resume_from_checkpoint = resume_from_checkpoint
+        self.do_eval_per_epoch = do_eval_per_epoch
+        self.config = config if config is not None else Namespace()
+        self.seed = seed
+        self.device = torch.device(device) if device is not None else \
+            torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.encoder_weights, self.decoder_weights, self.vgg_weights = encoder_weights, decoder_weights, vgg_weights
+        if self.with_tracking:
+            raise RuntimeError("wandb tracking is outside the hot path this build covers (SURVEY.md section 2)")
+        self.wandb = None
+        dist = _dist()
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world_size = dist.get_world_size() if dist is not None else 1
+
+    # ---- factories ------------------------------------------------------------------------
+    @staticmethod
+    def get_feature_extractor(selected_indices, vgg_model_type="19", device='cpu', weights=None):
+        from .loss_network import get_feature_extractor
+        return get_feature_extractor(selected_indices, vgg_model_type, device, weights)
+
+    @staticmethod
+    def get_optimizer(optimizer_name: str, parameters, learning_rate: float = 5e-5, kwargs: dict = None):
+        """trainer.py:201-232: ten torch optimizers by (case-insensitive) name; stock torch objects."""
+        optimizer_name = optimizer_name.lower()
+        kwargs_clone = dict(kwargs or {})
+        kwargs_clone.pop('optim_name', None)
+        table = {'sgd': optim.SGD, 'adam': optim.Adam, 'rmsprop': optim.RMSprop, 'adagrad': optim.Adagrad,
+                 'adadelta': optim.Adadelta, 'adamw': optim.AdamW, 'adamax': optim.Adamax,
+                 'sparseadam': optim.SparseAdam, 'lbfgs': optim.LBFGS, 'rprop': optim.Rprop}
+        if optimizer_name not in table:
+            raise ValueError(f"Optimizer '{optimizer_name}' not supported.")
+        try:
+            return table[optimizer_name](parameters, lr=learning_rate, **kwargs_clone)
+        except TypeError:
+            raise TypeError("Invalid argument for optimizer!")
+
+    def build_model(self):
+        """trainer.py:234-244 (one loss network serves both index lists)."""
+        encoder = Encoder(weights=self.encoder_weights).eval().to(self.device)
+        use_wct = self.use_pretrained_WCTDECODER if self.resume_from_checkpoint is None else False
+        decoder = Decoder(use_pretrained_WCT=use_wct, do_train=self.do_decoder_train,
+                          weights=self.decoder_weights).to(self.device)
+        transformer = AdaIN(eps=self.eps).to(self.device)
+        last = max(self.content_layers_idx + self.style_layers_idx)
+        loss_vgg = VGG19FeatureExtractor([last], weights=self.vgg_weights).to(self.device)
+        return encoder, decoder, transformer, loss_vgg
+
+    # ---- checkpoint -----------------------------------------------------------------------
+    def checkpoint_dict(self, transformer, transformer_optimizer, decoder, info):
+        """Exactly the dict of trainer.py:619-635."""
+        return {
+            'epoch': info['epoch'],
+            'model_state_dict': transformer.state_dict(),
+            "decoder_state_dict": decoder.state_dict() if decoder is not None else None,
+            'optimizer_state_dict': transformer_optimizer.state_dict(),
+            "optim_name": self.optim_name,
+            'loss': info['total'],
+            'completed_step': info['completed_step'],
+            "criterion": {"alpha": self.alpha, "beta": self.beta, "gamma": self.gamma, "delta": self.delta,
+                          "content_layers_idx": self.content_layers_idx, "style_layers_idx": self.style_layers_idx},
+        }
+
+    def save(self, transformer, transformer_optimizer, decoder=None, info=None, result=None):
+        """trainer.py:607-655: TotalL_.../transformer{N}.pth + config text; rank 0 only under DP."""
+        if self.rank != 0:
+            return None
+        dir_name = f"TotalL_{info['total']}_Content_{info['content']}_Style_{info['style']}"
+        save_path_dir = os.path.join(self.output_dir, dir_name)
+        print(f" Saving in {save_path_dir}")
+        if not os.path.exists(save_path_dir):
+            os.makedirs(save_path_dir, exist_ok=False)
+        else:
+            warnings.warn("File exist!, might be a good idea to change seed")
+            raise FileExistsError
+        n_examples = len(self.dataloaders['train'].dataset) if hasattr(self.dataloaders['train'], 'dataset') \
+            else len(self.dataloaders['train']) * self.per_device_batch_size
+        model_path = os.path.join(save_path_dir, f"transformer{n_examples}" + ".pth")
+        torch.save(self.checkpoint_dict(transformer, transformer_optimizer, decoder, info), model_path)
+        try:
+            stamp = '_'.join(str(datetime.datetime.now().strftime('%Y-%m-%d %H-%M-%S')).split())
+            with open(os.path.join(save_path_dir, f"config_E{info['epoch']}_{stamp}"), "w") as f:
+                f.write(f"\n          {PRJ_NAME}\n")
+                f.write(f"\n   Epoch: {info['epoch']}")
+                f.write(f"\n   Completed step: {info['completed_step']}")
+                f.write(f"\n   Loss: {info['total']}")
+                for key, value in vars(self.config).items():
+                    f.write(f"\n {key}: {value} ")
+        except IOError:
+            warnings.warn(f"Can't save config for this run {info['epoch']}")
+        if result is not None:
+            for idx, plot in enumerate(result):
+                plot.save(os.path.join(save_path_dir, f"result_plot{idx}.png"))
+        return model_path
+
+    def resume(self, transformer, decoder, transformer_optimizer):
+        """Resume rules of trainer.py:304-378.  Returns (optimizer, init_epoch, loss_list,
+        completed_step, last_session_epoch)."""
+        init_epoch, loss_list, completed_step, last_session_epoch = 0, [], 0, -1
+        if self.resume_from_checkpoint is None:
+            return transformer_optimizer, init_epoch, loss_list, completed_step, last_session_epoch
+        try:
+            checkpoint = torch.load(self.resume_from_checkpoint, map_location=self.device, weights_only=True)
+        except Exception:
+            raise RuntimeError("Unable to load from checkpoint, invalid path!")
+        try:
+            transformer.load_state_dict(checkpoint['model_state_dict'])
+        except Exception:
+            raise RuntimeError("Unable to load weight to the model, wrong model structure compare to checkpoint!")
+        try:
+            if checkpoint['decoder_state_dict'] is not None:
+                decoder.load_state_dict(checkpoint['decoder_state_dict'])
+        except Exception:
+            raise RuntimeError("Unable to load weight to the decoder model, wrong model structure compare to checkpoint!")
+        try:
+            ck_name = checkpoint['optim_name']['optim_name']
+            if self.optim_name['optim_name'] != ck_name:
+                params = list(transformer.parameters()) + (list(decoder.parameters()) if self.do_decoder_train else [])
+                transformer_optimizer = self.get_optimizer(ck_name, params, self.learning_rate, checkpoint['optim_name'])
+                warnings.warn(f"Set optim {self.optim_name['optim_name']} different from checkpoint optim {ck_name},"
+                              f" switching to {ck_name}")
+                self.optim_name['optim_name'] = ck_name
+            transformer_optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        except Exception:
+            raise RuntimeError("Unable to load optimizer state!")
+        try:
+            criterion = checkpoint['criterion']
+            if all(criterion[k] == getattr(self, k) for k in
+                   ('alpha', 'beta', 'gamma', 'delta', 'content_layers_idx', 'style_layers_idx')):
+                loss_list.append(checkpoint['loss'])
+            else:
+                warnings.warn("Last session loss discarded due to changed loss criteria")
+        except KeyError:
+            warnings.warn("checkpoint missing criterion info!")
+        try:
+            completed_step += checkpoint['completed_step']
+            last_session_epoch = checkpoint['epoch']
+            if last_session_epoch + 1 < self.num_train_epochs:
+                init_epoch = last_session_epoch + 1
+            else:
+                raise RuntimeError("Num train epoch can't be smaller than last session epoch resume from checkpoint!")
+        except KeyError:
+            warnings.warn("Checkpoint missing train process info!")
+        return transformer_optimizer, init_epoch, loss_list, completed_step, last_session_epoch
+
+    # ---- training -------------------------------------------------------------------------
+    def make_step(self, encoder, decoder, transformer, loss_vgg) -> StyleTransferStep:
+        return StyleTransferStep(encoder, decoder, transformer, loss_vgg, self.content_layers_idx,
+                                 self.style_layers_idx, self.alpha, self.beta, self.gamma, self.delta,
+                                 self.use_VincentStyleLoss)
+
+    def trainable_parameters(self, transformer, decoder):
+        params = list(transformer.parameters())
+        if self.do_decoder_train:
+            params += list(decoder.parameters())          # trainer.py:286-291
+        else:
+            for p in decoder.parameters():
+                p.requires_grad_(False)                   # never read by an optimizer (trainer.py:292-297)
+        return params
+
+    def optimize_step(self, step: StyleTransferStep, optimizer, bucket: GradBucket, content_imgs, style_imgs):
+        """zero_grad / backward / [grad all-reduce] / [AdaIN grad clamp] / optimizer.step (trainer.py:471-473, 392-394)."""
+        global_batch = content_imgs.shape[0] * self.world_size
+        losses = step.forward_losses(content_imgs, style_imgs, global_batch)
+        optimizer.zero_grad()
+        losses[4].backward()
+        bucket.reduce_mean()
+        if self.gradient_threshold is not None:
+            for p in step.transformer.parameters():
+                if p.grad is not None:
+                    p.grad.clamp_(-self.gradient_threshold, self.gradient_threshold)
+        optimizer.step()
+        return losses
+
+    def train(self):
+        encoder, decoder, transformer, loss_vgg = self.build_model()
+        params = self.trainable_parameters(transformer, decoder)
+        transformer_optimizer = self.get_optimizer(self.optim_name['optim_name'], params, self.learning_rate,
+                                                   self.optim_name)
+        transformer_optimizer, init_epoch, loss_list, completed_step, last_session_epoch = \
+            self.resume(transformer, decoder, transformer_optimizer)
+        train_loader = self.dataloaders['train']
+        steps_per_epoch = len(train_loader)
+        scheduler = lr_scheduler.CosineAnnealingLR(
+            transformer_optimizer, T_max=steps_per_epoch * (self.num_train_epochs - init_epoch),
+            last_epoch=last_session_epoch if self.resume_from_checkpoint else -1)
+        scheduler_steps = math.ceil(steps_per_epoch * self.step_frequency)       # trainer.py:387
+        scheduler_count = 0
+        step_engine = self.make_step(encoder, decoder, transformer, loss_vgg)
+        bucket = GradBucket(params)
+        history = []
+        for epoch in range(init_epoch, self.num_train_epochs):
+            sums = torch.zeros(5, dtype=torch.float64, device=self.device)
+            transformer.train()
+            if self.do_decoder_train:
+                decoder.train()
+            for step, batch in enumerate(train_loader):
+                content_imgs = batch['content_image'].to(self.device, non_blocking=True).contiguous()
+                style_imgs = batch['style_image'].to(self.device, non_blocking=True).contiguous()
+                losses = self.optimize_step(step_engine, transformer_optimizer, bucket, content_imgs, style_imgs)
+                completed_step += step                                          # trainer.py:475 (sic: index, not 1)
+                sums += torch.stack([l.detach().double().reshape(()) for l in losses])
+                scheduler_count += 1
+                if scheduler_count >= scheduler_steps:                          # trainer.py:498-502
+                    scheduler.step()
+                    scheduler_count = 0
+            avg = (sums / steps_per_epoch).tolist()                              # one device->host read per epoch
+            avg_content, avg_style, avg_var, avg_hist, avg_total = avg
+            loss_list.append(avg_total)
+            history.append({"epoch": epoch, "content": avg_content, "style": avg_style, "variation": avg_var,
+                            "hist": avg_hist, "total": avg_total})
+            if self.rank == 0:
+                epss = transformer.get_current_eps()
+                print(f"   Epoch [{epoch + 1}/{self.num_train_epochs}] total {avg_total} content {avg_content} "
+                      f"style {avg_style} variation {avg_var} hist {avg_hist} eps(style, content) {epss}")
+            info = {"total": avg_total, "content": avg_content, "style": avg_style, "epoch": epoch,
+                    "completed_step": completed_step}
+            if (avg_total == min(loss_list) and self.save_best) or not self.save_best:   # trainer.py:580-595
+                self.save(transformer, transformer_optimizer, decoder, info=info, result=None)
+        return history
+
+    # ---- inference composition --------------------------------------------------------------
+    @staticmethod
+    @torch.no_grad()
+    def stylize(encoder, decoder, transformer, content: torch.Tensor, style: torch.Tensor, alpha: float = 1.0,
+                normalize: bool = True):
+        """The tensor part of plot_comparison (trainer.py:695-708) on batched inputs."""
+        from .pipeline import stylize
+        out = stylize(encoder, decoder, transformer, content, style, alpha)
+        return Normalize(IMAGENET_MEAN, IMAGENET_STD)(out) if normalize else out

@@ -1,0 +1,142 @@
+"""CPU tests: C-ABI exports, host-side shapes/keys, checkpoint layout, and the data-parallel
+reductions on gloo with world_size 2 (no HIP compute is launched here)."""
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from style_transfer_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "st_hip.h")).read()
+    declared = set(re.findall(r"\b(st_[a-z0-9_]+)\s*\(", hdr))
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in st_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == declared
+    assert lib.st_version() >= 100
+    assert lib.st_conv3x3_packed_elems(64, 3) == 8 * 9 * 128
+    assert lib.st_conv3x3_packed_elems(512, 256) == 256 * 9 * 512
+    assert lib.st_conv3x3_dgrad_workspace_bytes(2, 8, 6, 5, 0) == 2 * 8 * 8 * 7 * 4
+    assert lib.st_conv3x3_dgrad_workspace_bytes(2, 8, 6, 5, 1) == 0
+
+
+def test_bad_arguments_return_errors_not_crashes():
+    from style_transfer_amd import _lib
+    lib = _lib.load()
+    assert lib.st_conv3x3_fwd(None, None, None, None, 1, 1, 1, 1, 1, 0, 0, 0, None) == -1
+    assert b"null pointer" in lib.st_last_error()
+    assert lib.st_adain_fwd(None, None, None, 1, 1, 1, 1, 1e-5, 1e-5, 1.0, None, None) == -1
+
+
+def test_module_surface_and_state_dict_keys():
+    from oracle import ref_ops as R
+    from style_transfer_amd.generator import Decoder, Encoder, SymmetricPadding2D
+    from style_transfer_amd.transformer import AdaIN
+    enc = Encoder(weights=R.make_encoder_state(0))
+    assert [k for k in enc.state_dict()] == ["encode." + k for k in R.make_encoder_state(0)]
+    assert not any(p.requires_grad for p in enc.parameters())
+    with pytest.raises(FileNotFoundError):
+        Encoder()                                          # same failure as the reference without the blob
+    dec = Decoder()
+    assert list(dec.state_dict()) == list(R.make_decoder_state(1))
+    assert sum(p.numel() for p in dec.parameters()) == 3505219
+    ada = AdaIN()
+    assert ada.eps_limit == 1e-5 and list(ada.state_dict()) == ["content_eps", "style_eps"]
+    assert AdaIN.adjust_sigmoid(torch.tensor([1e-12]), 0.3) == 1e-5
+    assert AdaIN.adjust_sigmoid(torch.tensor([0.5]), 0.3) == 0.3
+    assert isinstance(AdaIN.adjust_sigmoid(torch.tensor([0.01]), 0.3), torch.Tensor)
+    assert SymmetricPadding2D().padding == (1, 1, 1, 1)
+
+
+def test_checkpoint_roundtrip_cpu(tmp_path):
+    from argparse import Namespace
+    from style_transfer_amd.generator import Decoder
+    from style_transfer_amd.trainer import Trainer
+    from style_transfer_amd.transformer import AdaIN
+
+    class Loader(list):
+        dataset = list(range(7))
+
+    tr = Trainer({"train": Loader()}, output_dir=str(tmp_path), num_train_epochs=5, per_device_batch_size=2,
+                 learning_rate=1e-4, alpha=1, beta=10, gamma=1, delta=10, config=Namespace(seed=42), device="cpu",
+                 optim_name={"optim_name": "adam"}, do_decoder_train=True)
+    ada, dec = AdaIN(0.1), Decoder()
+    opt = Trainer.get_optimizer("adam", list(ada.parameters()) + list(dec.parameters()), 1e-4, {"optim_name": "adam"})
+    path = tr.save(ada, opt, dec, info={"total": 1.5, "content": 0.5, "style": 0.25, "epoch": 1, "completed_step": 3})
+    assert path.endswith(os.path.join("TotalL_1.5_Content_0.5_Style_0.25", "transformer7.pth"))
+    with pytest.raises(FileExistsError):
+        tr.save(ada, opt, dec, info={"total": 1.5, "content": 0.5, "style": 0.25, "epoch": 1, "completed_step": 3})
+    cfg = [f for f in os.listdir(os.path.dirname(path)) if f.startswith("config_E1_")]
+    assert len(cfg) == 1
+    tr.resume_from_checkpoint = path
+    opt2, init_epoch, loss_list, completed, last_epoch = tr.resume(AdaIN(0.1), Decoder(), opt)
+    assert (init_epoch, loss_list, completed, last_epoch) == (2, [1.5], 3, 1)
+    tr.alpha = 2                                             # changed criterion: last loss discarded
+    with pytest.warns(UserWarning):
+        assert tr.resume(AdaIN(0.1), Decoder(), opt)[2] == []
+    tr.num_train_epochs = 2
+    with pytest.raises(RuntimeError):
+        tr.resume(AdaIN(0.1), Decoder(), opt)
+    with pytest.raises(ValueError):
+        Trainer.get_optimizer("nope", ada.parameters(), 1e-4, {"optim_name": "nope"})
+
+
+# ---- data parallel on gloo, world_size 2 -------------------------------------------------------
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    from oracle import ref_ops as R
+    from style_transfer_amd.trainer import GradBucket, allreduce_q
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    # a tiny "decoder": image = w * x + b; losses: TV (per-sample mean) + exact global HistLoss
+    w = torch.nn.Parameter(torch.tensor([0.8, 1.1, 0.9]).view(1, 3, 1, 1))
+    b = torch.nn.Parameter(torch.tensor([0.05, -0.02, 0.01]).view(1, 3, 1, 1))
+    g = torch.Generator().manual_seed(11)
+    x_all = torch.rand(4, 3, 12, 12, generator=g)
+    t_all = torch.rand(4, 3, 12, 12, generator=g)
+
+    def loss_fn(x, t, reduce_q, global_batch):
+        img = w * x + b
+        ih, th = R.rgbuv_hist(img), R.rgbuv_hist(t)
+        qv = torch.sum((torch.sqrt(th) - torch.sqrt(ih)) ** 2)
+        qv = reduce_q(qv)
+        hist = (1 / (2.0 ** 0.5) * torch.sqrt(qv) / global_batch) * 100
+        return R.tv_loss(img) + 10.0 * hist
+
+    lo, hi = rank * 2, rank * 2 + 2
+    loss = loss_fn(x_all[lo:hi], t_all[lo:hi], allreduce_q, 4)
+    loss.backward()
+    GradBucket([w, b]).reduce_mean()
+    dp = torch.cat([w.grad.flatten(), b.grad.flatten()]).clone()
+    w.grad = None; b.grad = None
+    full = loss_fn(x_all, t_all, lambda v: v, 4)
+    full.backward()
+    ref = torch.cat([w.grad.flatten(), b.grad.flatten()])
+    if rank == 0:
+        q.put((dp.tolist(), ref.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_large_batch():
+    """Batch sharded over 2 ranks + bucket mean all-reduce + all-reduced Hellinger scalar ==
+    single-process gradients on the whole batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    dp, ref = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.testing.assert_close(torch.tensor(dp), torch.tensor(ref), rtol=2e-4, atol=1e-6)
