@@ -1,17 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: stylised 512x512 images per second (inference), BASELINE.json configs[1]
-(batch 16, fp32, one MI355X); for N > 1 every rank stylises its own batch of 16 (images are
-independent: no data-path collective, weak scaling).
+"""Headline benchmark of the AdaIN style-transfer hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode both|infer|train]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task brief) with two extra objects:
-  roofline     -- the dominant kernel (fp32 MFMA conv3x3, 128-channel tile instantiation):
-                  algorithmic FLOPs per launch / average launch duration, measured with HIP
-                  events on the launch stream inside the timed region;
-  cpu_baseline -- the CPU oracle (oracle/ref_ops.py, a port of the reference's torch path)
-                  timed on this box's host cores on a bounded sample of the same workload.
+BASELINE.json's metric has two halves and rank 0 prints ONE JSON line carrying both:
+
+  * top-level fields  -- "stylized 512x512 img/s (inference)": BASELINE configs[1], batch 16 at
+    512x512 fp32 per GPU (2x encoder + AdaIN + decoder, alpha = 1).  For N > 1 every rank stylises
+    its own batch of 16 (images are independent: no data-path collective, weak scaling).
+    EXACTLY --steps timed steps after --warmup, barrier + synchronize on both sides, max over ranks.
+  * "train" object    -- "train img/s": BASELINE configs[2], batch 8 at 256x256 fp32 per GPU, the full
+    training step (2x encoder, AdaIN, decoder, Normalize, loss VGG19, content MSE + mean/std style +
+    TV + RGB-uv histogram losses, backward, RCCL bucket all-reduce when N > 1, Adam step), timed the
+    same way with its own steps; "gram" inside it is the same step with --use_VincentStyleLoss
+    (covariance "Gram" MFMA kernel + eigh).
+
+Extra objects (task brief, section 4):
+  roofline     -- the dominant kernel (fp32 MFMA conv3x3, 128-channel tile instantiation): algorithmic
+                  FLOPs per launch / average launch duration, measured with HIP events on the launch
+                  stream inside the timed region; `traffic` = HBM bytes per launch from the committed
+                  PMC passes (profiles/, FETCH_SIZE + WRITE_SIZE), not collected live.
+  roofline_adain -- the HBM-bound AdaIN kernel: algorithmic bytes (read content, read style, write
+                  out) / average launch duration against the 8 TB/s HBM3E peak.
+  cpu_baseline -- the CPU oracle (oracle/ref_ops.py, a port of the reference's torch path) timed on
+                  this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -20,6 +33,7 @@ import json
 import os
 import sys
 import time
+import warnings
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -27,15 +41,20 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
-BATCH = 16
-SIDE = 512
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BATCH, SIDE = 16, 512           # configs[1]
+TRAIN_BATCH, TRAIN_SIDE = 8, 256  # configs[2]
+CONTENT_IDX, STYLE_IDX = [21], [2, 7, 14, 19, 25]   # CLI defaults, train.py:80-83
+DOMINANT = "conv3x3_f32_kernel<2,2,2,2>"
+# HBM bytes per launch of the dominant kernel from profiles/r1_bench_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
+# KiB, averaged over its 20 launches per inference step; 4-B-per-lane loads: FETCH_SIZE taken as reported)
+DOMINANT_TRAFFIC_BYTES = (833662.017 + 298188.8) * 1024
 
 
-def encoder_decoder_flops(side: int) -> float:
-    """Algorithmic FLOPs (2*MAC) per stylised image: 2 x encoder + decoder (379.61 GF @512)."""
+def encoder_decoder_flops(side: int):
+    """Algorithmic FLOPs (2*MAC) per image of (encoder, decoder) (126.54 / 126.53 GF @512)."""
     from oracle.ref_ops import DECODER_CONVS, DECODER_UP_AFTER, ENCODER_CONVS, ENCODER_POOL_AFTER
-    enc = 0.0
-    h = side
+    enc, h = 0.0, side
     for idx, cin, cout, k in ENCODER_CONVS:
         enc += 2.0 * h * h * cin * cout * k * k
         if idx in ENCODER_POOL_AFTER:
@@ -45,10 +64,31 @@ def encoder_decoder_flops(side: int) -> float:
         dec += 2.0 * h * h * cin * cout * 9
         if idx in DECODER_UP_AFTER:
             h *= 2
-    return 2 * enc + dec
+    return enc, dec
 
 
-def cpu_baseline(pairs: int = 2, runs: int = 2):
+def loss_vgg_flops(side: int, upto: int) -> float:
+    from oracle.ref_ops import VGG19_FEATURES
+    f, h = 0.0, side
+    for idx, (kind, cin, cout) in enumerate(VGG19_FEATURES):
+        if idx > upto:
+            break
+        if kind == "conv":
+            f += 2.0 * h * h * cin * cout * 9
+        elif kind == "pool":
+            h //= 2
+    return f
+
+
+def train_flops_per_image(side: int) -> float:
+    """Necessary work of one training step per image (405.95 GF @256, 1623.8 GF @512):
+    fwd 2E + D + 2 L@21 + 2 L@25; bwd decoder dgrad + wgrad (2D) + loss-VGG dgrad on the decoded passes."""
+    enc, dec = encoder_decoder_flops(side)
+    l21, l25 = loss_vgg_flops(side, max(CONTENT_IDX)), loss_vgg_flops(side, max(STYLE_IDX))
+    return (2 * enc + dec + 2 * l21 + 2 * l25) + 2 * dec + (l21 + l25)
+
+
+def cpu_baseline_infer(pairs: int = 2, runs: int = 2):
     """Time the CPU oracle on a bounded sample: `pairs` 512x512 content/style pairs, alpha=1."""
     from oracle import ref_ops as R
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
@@ -70,6 +110,193 @@ def cpu_baseline(pairs: int = 2, runs: int = 2):
                       f"of oracle.ref_ops.stylize (plain torch CPU, {cores} threads)"}
 
 
+def cpu_baseline_train(batch: int = 2, runs: int = 2):
+    """One full training step (forward, losses, backward, Adam) of the CPU oracle at batch 2, 256x256."""
+    from oracle import ref_ops as R
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    enc_sd = R.make_encoder_state(0)
+    dec_sd = {k: v.clone().requires_grad_(True) for k, v in R.make_decoder_state(1).items()}
+    vgg_sd = R.make_loss_vgg_state(2, upto=max(STYLE_IDX))
+    ce = torch.tensor([1e-5], requires_grad=True)
+    se = torch.tensor([1e-5], requires_grad=True)
+    params = list(dec_sd.values()) + [ce, se]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    c = torch.rand(batch, 3, TRAIN_SIDE, TRAIN_SIDE, generator=g)
+    s = torch.rand(batch, 3, TRAIN_SIDE, TRAIN_SIDE, generator=g)
+    times = []
+    for i in range(runs + 1):
+        t0 = time.perf_counter()
+        losses = R.train_step_losses(c, s, enc_sd, dec_sd, vgg_sd, ce, se, 0.1, CONTENT_IDX, STYLE_IDX,
+                                     1.0, 10.0, 1.0, 10.0, False)
+        opt.zero_grad()
+        losses[4].backward()
+        opt.step()
+        if i:
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(batch / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"one training step at batch {batch}, {TRAIN_SIDE}x{TRAIN_SIDE} fp32 (mean/std style loss), "
+                      f"best of {runs} after 1 warm-up, oracle.ref_ops.train_step_losses + autograd + Adam "
+                      f"(plain torch CPU, {cores} threads)"}
+
+
+class Ctx:
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (the HIP hot path has no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=self.dev)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def timed(ctx: Ctx, fn, steps: int, warmup: int, collect_kernels: bool):
+    from style_transfer_amd import ops
+    for _ in range(warmup):
+        fn()
+    ctx.barrier()
+    if collect_kernels:
+        ops.KERNEL_TIMER.start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    records = ops.KERNEL_TIMER.stop() if collect_kernels else []
+    return ctx.max_over_ranks(elapsed), records, out
+
+
+def run_inference(ctx: Ctx, args):
+    from oracle import ref_ops as R     # seeded synthetic weights only
+    from style_transfer_amd.generator import Decoder, Encoder
+    from style_transfer_amd.pipeline import stylize
+    from style_transfer_amd.transformer import AdaIN
+
+    dev = ctx.dev
+    enc = Encoder(weights=R.make_encoder_state(0)).to(dev).eval()
+    dec = Decoder().to(dev).eval()
+    dec.load_state_dict(R.make_decoder_state(1))
+    ada = AdaIN().to(dev)
+    g = torch.Generator().manual_seed(1234 + ctx.rank)
+    content = torch.rand(args.batch, 3, args.side, args.side, generator=g).to(dev)   # resident in HBM
+    style = torch.rand(args.batch, 3, args.side, args.side, generator=g).to(dev)
+
+    elapsed, records, out = timed(ctx, lambda: stylize(enc, dec, ada, content, style, alpha=1.0),
+                                  args.steps, args.warmup, collect_kernels=True)
+    assert torch.isfinite(out).all()
+    value = ctx.world * args.batch * args.steps / elapsed
+    e_f, d_f = encoder_decoder_flops(args.side)
+    per_img = 2 * e_f + d_f
+
+    dom = [r for r in records if r["kernel"] == DOMINANT]
+    allconv = [r for r in records if r["kernel"].startswith("conv3x3_f32_kernel")]
+    flops = sum(r["flops"] for r in dom)
+    secs = sum(r["ms"] for r in dom) * 1e-3
+    achieved = flops / secs / 1e12 if secs > 0 else 0.0
+    default_shape = args.batch == BATCH and args.side == SIDE
+    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": round(DOMINANT_TRAFFIC_BYTES) if default_shape else None,
+            "traffic_note": "HBM bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r1_bench_pmc_hbm.csv "
+                            "(separate --pmc passes of this command)",
+            "kernel": DOMINANT, "launches": len(dom),
+            "avg_launch_us": round(secs / max(1, len(dom)) * 1e6, 2),
+            "avg_launch_gflop": round(flops / max(1, len(dom)) / 1e9, 3),
+            "all_conv_tflops": round(sum(r["flops"] for r in allconv) /
+                                     max(1e-12, sum(r["ms"] for r in allconv) * 1e-3) / 1e12, 2),
+            "all_conv_time_frac_of_step": round(sum(r["ms"] for r in allconv) * 1e-3 / elapsed, 4)}
+    ad = [r for r in records if r["kernel"].startswith("adain")]
+    ad_bytes = sum(r["bytes"] for r in ad)
+    ad_secs = sum(r["ms"] for r in ad) * 1e-3
+    ad_gbs = ad_bytes / ad_secs / 1e9 if ad_secs > 0 else 0.0
+    roof_adain = {"bound": "hbm", "achieved": round(ad_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(ad_gbs / HBM_PEAK_GBS, 4), "kernel": "adain_reg_kernel<4>", "launches": len(ad),
+                  "avg_launch_us": round(ad_secs / max(1, len(ad)) * 1e6, 2),
+                  "avg_launch_mbytes": round(ad_bytes / max(1, len(ad)) / 1e6, 2),
+                  "traffic": round(ad_bytes / max(1, len(ad))) if default_shape else None,
+                  "traffic_note": "PMC: 2 x FETCH_SIZE (gfx950 16-B/lane correction) + WRITE_SIZE = 402.7 MB = "
+                                  "algorithmic bytes (profiles/r1_bench_pmc_hbm.csv)"}
+    return {
+        "metric": "stylized 512x512 img/s (inference)", "value": round(value, 3), "unit": "img/s",
+        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: inference batch {args.batch} at {args.side}x{args.side} "
+                               "fp32 per GPU, 2x VGG19-relu4_1 encoder + AdaIN + decoder, alpha=1",
+                   "batch_per_gpu": args.batch, "side": args.side,
+                   "parallelism": f"images sharded x{ctx.world}, no collective",
+                   "gflop_per_image": round(per_img / 1e9, 2)},
+        "model_tflops": round(value * per_img / 1e12, 2),
+        "roofline": roof, "roofline_adain": roof_adain,
+    }
+
+
+def run_train(ctx: Ctx, args, use_vincent: bool):
+    from oracle import ref_ops as R     # seeded synthetic weights only
+    from style_transfer_amd.trainer import GradBucket, Trainer
+
+    dev = ctx.dev
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = Trainer({"train": []}, output_dir="/tmp/st_bench", num_train_epochs=1,
+                     per_device_batch_size=args.train_batch, learning_rate=1e-4, alpha=1.0, beta=10.0, gamma=1.0,
+                     delta=10.0, eps=0.1, do_decoder_train=True, optim_name={"optim_name": "adam"},
+                     use_VincentStyleLoss=use_vincent, content_layers_idx=CONTENT_IDX, style_layers_idx=STYLE_IDX,
+                     encoder_weights=R.make_encoder_state(0), vgg_weights=R.make_loss_vgg_state(2, upto=max(STYLE_IDX)),
+                     device=dev)
+        encoder, decoder, transformer, loss_vgg = tr.build_model()
+        decoder.load_state_dict(R.make_decoder_state(1))
+        params = tr.trainable_parameters(transformer, decoder)
+        opt = tr.get_optimizer("adam", params, 1e-4, {"optim_name": "adam"})
+        step = tr.make_step(encoder, decoder, transformer, loss_vgg)
+    bucket = GradBucket(params)
+    g = torch.Generator().manual_seed(4321 + ctx.rank)
+    s = args.train_side
+    content = torch.rand(args.train_batch, 3, s, s, generator=g).to(dev)
+    style = torch.rand(args.train_batch, 3, s, s, generator=g).to(dev)
+
+    def one():
+        return tr.optimize_step(step, opt, bucket, content, style)
+
+    steps, warmup = args.train_steps, args.train_warmup
+    elapsed, _, losses = timed(ctx, one, steps, warmup, collect_kernels=False)
+    total = float(losses[4].detach())
+    assert total == total, "training loss is NaN"
+    value = ctx.world * args.train_batch * steps / elapsed
+    per_img = train_flops_per_image(s)
+    return {"metric": "train img/s", "value": round(value, 3), "unit": "img/s", "n_gpus": ctx.world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "scaling": "weak",
+            "dtype": "f32", "style_loss": "VincentStyleLoss (covariance MFMA + eigh)" if use_vincent
+            else "AdaINStyleLoss (mean/std)",
+            "config": {"workload": f"BASELINE configs[2]: training step batch {args.train_batch} at {s}x{s} fp32 per "
+                                   "GPU: 2x encoder, AdaIN, decoder, Normalize, loss VGG19 (idx 21 / 2,7,14,19,25), "
+                                   "content + style + TV + RGB-uv histogram losses, backward, Adam(decoder + eps)",
+                       "batch_per_gpu": args.train_batch, "side": s,
+                       "parallelism": f"dp{ctx.world}: batch sharded, one 14.02 MB fp32 RCCL all-reduce + 2 scalar "
+                                      "all-reduces per step" if ctx.world > 1 else "single GPU",
+                       "gflop_per_image_necessary": round(per_img / 1e9, 2)},
+            "model_tflops": round(value * per_img / 1e12, 2), "final_total_loss": round(total, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,93 +304,39 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--side", type=int, default=SIDE)
+    ap.add_argument("--mode", choices=["both", "infer", "train"], default="both")
+    ap.add_argument("--train-batch", type=int, default=TRAIN_BATCH)
+    ap.add_argument("--train-side", type=int, default=TRAIN_SIDE)
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--no-gram", action="store_true", help="skip the VincentStyleLoss variant of the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the HIP hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
-    from oracle import ref_ops as R     # seeded synthetic weights only
-    from style_transfer_amd import ops
-    from style_transfer_amd.generator import Decoder, Encoder
-    from style_transfer_amd.pipeline import stylize
-    from style_transfer_amd.transformer import AdaIN
-
-    enc = Encoder(weights=R.make_encoder_state(0)).to(dev).eval()
-    dec = Decoder().to(dev).eval()
-    dec.load_state_dict(R.make_decoder_state(1))
-    ada = AdaIN().to(dev)
-
-    g = torch.Generator().manual_seed(1234 + rank)
-    content = torch.rand(args.batch, 3, args.side, args.side, generator=g).to(dev)   # resident in HBM
-    style = torch.rand(args.batch, 3, args.side, args.side, generator=g).to(dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        stylize(enc, dec, ada, content, style, alpha=1.0)
-    barrier()
-    ops.KERNEL_TIMER.start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = stylize(enc, dec, ada, content, style, alpha=1.0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    records = ops.KERNEL_TIMER.stop()
-    assert torch.isfinite(out).all()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    total_imgs = world * args.batch * args.steps
-    value = total_imgs / elapsed
-
-    if rank == 0:
-        # dominant kernel: the 128-channel-tile instantiation of the fp32 MFMA conv
-        dom = [r for r in records if r["kernel"] == "conv3x3_f32_kernel<2,2,2,2>"]
-        allconv = [r for r in records if r["kernel"].startswith("conv3x3_f32_kernel")]
-        flops = sum(r["flops"] for r in dom)
-        secs = sum(r["ms"] for r in dom) * 1e-3
-        achieved = flops / secs / 1e12 if secs > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": "conv3x3_f32_kernel<2,2,2,2>", "launches": len(dom),
-                "avg_launch_us": round(secs / max(1, len(dom)) * 1e6, 2),
-                "avg_launch_gflop": round(flops / max(1, len(dom)) / 1e9, 3),
-                "all_conv_tflops": round(sum(r["flops"] for r in allconv) /
-                                         max(1e-12, sum(r["ms"] for r in allconv) * 1e-3) / 1e12, 2),
-                "all_conv_time_frac_of_step": round(sum(r["ms"] for r in allconv) * 1e-3 / elapsed, 4)}
-        line = {
-            "metric": "stylized 512x512 img/s (inference)", "value": round(value, 3), "unit": "img/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: inference batch {args.batch} at {args.side}x{args.side} "
-                                   "fp32 per GPU, 2x VGG19-relu4_1 encoder + AdaIN + decoder, alpha=1",
-                       "batch_per_gpu": args.batch, "side": args.side, "parallelism": f"images sharded x{world}, "
-                       "no collective", "gflop_per_image": round(encoder_decoder_flops(args.side) / 1e9, 2)},
-            "model_tflops": round(value * encoder_decoder_flops(args.side) / 1e12, 2),
-            "roofline": roof,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+    ctx = Ctx()
+    line = {}
+    if args.mode in ("both", "infer"):
+        line = run_inference(ctx, args)
+    if args.mode in ("both", "train"):
+        train = run_train(ctx, args, use_vincent=False)
+        if not args.no_gram:
+            train["gram"] = run_train(ctx, args, use_vincent=True)
+        if args.mode == "train":
+            line = dict(train, higher_is_better=True, vs_baseline=None, data="synthetic")
+            train = None
+        if train is not None:
+            line["train"] = train
+    if ctx.rank == 0:
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            if args.mode in ("both", "infer"):
+                line["cpu_baseline"] = cpu_baseline_infer()
+            if args.mode in ("both", "train"):
+                tgt = line["train"] if args.mode == "both" else line
+                tgt["cpu_baseline"] = cpu_baseline_train()
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -217,11 +217,16 @@ def adain(content: torch.Tensor, style: torch.Tensor, eps_content: float, eps_st
     hs, ws = int(style.shape[2]), int(style.shape[3])
     out = torch.empty_like(content)
     stats = torch.empty((n * c, 4), dtype=torch.float32, device=content.device) if save_stats else None
+    ev = None
+    if KERNEL_TIMER.enabled:   # algorithmic bytes: read content once, read style once, write out once
+        ev = KERNEL_TIMER.record("adain_fwd", 0.0, 4.0 * (2 * content.numel() + style.numel()))
     _lib.check(lib.st_adain_fwd(_lib.dev_ptr(content, "content"), _lib.dev_ptr(style, "style"),
                                 _lib.dev_ptr(out, "out"), n, c, hc * wc, hs * ws, float(eps_content),
                                 float(eps_style), float(alpha),
                                 _lib.dev_ptr(stats, "stats") if stats is not None else None,
                                 _lib.stream_ptr()), "st_adain_fwd")
+    if ev is not None:
+        ev.record()
     return out, stats
 
 
