@@ -97,6 +97,23 @@ int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_gate, float
                      float* dbias, float* workspace, int n, int cin, int hin, int win, int cout,
                      int upsample2x, int pad_mode, st_stream_t stream);
 
+/* ---- bf16 compute mode of the same layers (BASELINE config 4: bf16 compute, fp32 master) ------
+ * Same layer semantics, shapes and fp32 NCHW activations as st_conv3x3_fwd / st_conv3x3_dgrad
+ * above (generator.py:47-76, 89-117; trainer.py:165-199); only the MFMA operands are bf16:
+ * activations are rounded to nearest-even while staged into LDS, weights when packed, products
+ * accumulate in fp32 (v_mfma_f32_32x32x16_bf16).  The packed buffer holds
+ * st_conv3x3_packed_elems_bf16() 2-byte elements and must be 16-byte aligned. */
+size_t st_conv3x3_packed_elems_bf16(int cout, int cin);
+int st_conv3x3_pack_weights_bf16(const float* w_oihw, void* w_packed, int cout, int cin,
+                                 int transpose_flip, st_stream_t stream);
+int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* y,
+                        int n, int cin, int hin, int win, int cout,
+                        int upsample2x, int pad_mode, int relu, st_stream_t stream);
+/* workspace: st_conv3x3_dgrad_workspace_bytes() (same as the fp32 entry point) */
+int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t, float* dx,
+                          float* workspace, int n, int cout, int h, int w, int cin, int upsample2x,
+                          int pad_mode, st_stream_t stream);
+
 /* ---- SymmetricPadding2D.forward, any padding (generator.py:14-39) ----------------------
  * numpy-"symmetric" reflection about the half-pixel points -0.5 and n-0.5 (edge pixel
  * repeated).  x: [nc][h][w] -> y: [nc][h+top+bottom][w+left+right].  The fused 3x3 conv

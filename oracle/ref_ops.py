@@ -70,6 +70,58 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
 # --------------------------------------------------------------------------
+# conv operand precision (fp32 = the reference; "bf16" emulates the HIP bf16 compute mode)
+# --------------------------------------------------------------------------
+
+CONV_COMPUTE = "f32"
+
+
+class conv_compute:
+    """Context manager: ``with conv_compute("bf16"):`` makes every 3x3 convolution of this module
+    round its operands (activations, weights, and the output gradient in the data-gradient) to
+    bf16 with fp32 accumulation -- the numerics of style_transfer_amd's bf16 compute mode
+    (csrc/conv3x3_bf16.hip); the weight gradient stays fp32 like the HIP path."""
+
+    def __init__(self, name: str):
+        assert name in ("f32", "bf16")
+        self.name = name
+
+    def __enter__(self):
+        global CONV_COMPUTE
+        self.prev, CONV_COMPUTE = CONV_COMPUTE, self.name
+
+    def __exit__(self, *exc):
+        global CONV_COMPUTE
+        CONV_COMPUTE = self.prev
+
+
+def _round_bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _ConvBf16Operands(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, w, b):
+        ctx.save_for_backward(xp, w)
+        return F.conv2d(_round_bf16(xp), _round_bf16(w), b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, w = ctx.saved_tensors
+        gx = torch.nn.grad.conv2d_input(xp.shape, _round_bf16(w), _round_bf16(gy)) if ctx.needs_input_grad[0] else None
+        gw = torch.nn.grad.conv2d_weight(xp, w.shape, gy) if ctx.needs_input_grad[1] else None
+        gb = gy.sum((0, 2, 3)) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def conv3x3_padded(xp: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d(cin, cout, (3,3)) on an already padded input (generator.py:48 etc.)."""
+    if CONV_COMPUTE == "bf16":
+        return _ConvBf16Operands.apply(xp, w, b)
+    return F.conv2d(xp, w, b)
+
+
+# --------------------------------------------------------------------------
 # generator.py
 # --------------------------------------------------------------------------
 
@@ -103,7 +155,7 @@ def encoder_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tenso
         if k == 1:
             x = F.conv2d(x, w, b)
         else:
-            x = F.relu(F.conv2d(symmetric_pad(x), w, b))
+            x = F.relu(conv3x3_padded(symmetric_pad(x), w, b))
         if idx in ENCODER_POOL_AFTER:
             x = F.max_pool2d(x, 2, 2, 0, ceil_mode=True)
     return x
@@ -113,7 +165,7 @@ def decoder_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = 
     """Decoder.forward (generator.py:85-130).  Keys ``decoder.{1,...,28}.{weight,bias}``."""
     for idx, _cin, _cout in DECODER_CONVS:
         w, b = sd[f"{prefix}{idx}.weight"], sd[f"{prefix}{idx}.bias"]
-        x = F.conv2d(symmetric_pad(x), w, b)
+        x = conv3x3_padded(symmetric_pad(x), w, b)
         if idx != 28:
             x = F.relu(x)
         if idx in DECODER_UP_AFTER:
@@ -236,7 +288,7 @@ def loss_vgg_features(x: torch.Tensor, sd: Dict[str, torch.Tensor], indices: Seq
     outs: Dict[int, torch.Tensor] = {}
     for idx, (kind, _cin, _cout) in enumerate(VGG19_FEATURES[: last + 1]):
         if kind == "conv":
-            x = F.conv2d(x, sd[f"{idx}.weight"], sd[f"{idx}.bias"], padding=1)
+            x = conv3x3_padded(F.pad(x, (1, 1, 1, 1)), sd[f"{idx}.weight"], sd[f"{idx}.bias"])
         elif kind == "relu":
             x = F.relu(x)
             if idx - 1 in outs:          # in-place aliasing of the captured conv output

@@ -25,6 +25,12 @@ SIGNATURES = {
     "st_conv3x3_dgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_packed_elems_bf16": (c_size_t, [c_int, c_int]),
+    "st_conv3x3_pack_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_dgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_void_p]),
@@ -96,15 +102,15 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def dev_ptr(t: torch.Tensor, name: str = "tensor") -> int:
-    """Raw device pointer of a contiguous fp32 HIP tensor (loud failure otherwise)."""
+def dev_ptr(t: torch.Tensor, name: str = "tensor", dtype=torch.float32) -> int:
+    """Raw device pointer of a contiguous HIP tensor of `dtype` (fp32 by default; loud failure otherwise)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
     if not t.is_cuda:
         raise StHipError(f"{name}: the HIP hot path needs a tensor on the GPU, got device={t.device} "
                          "(no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
-    if t.dtype != torch.float32:
-        raise StHipError(f"{name}: expected float32, got {t.dtype}")
+    if t.dtype != dtype:
+        raise StHipError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise StHipError(f"{name}: expected a contiguous tensor")
     return t.data_ptr()

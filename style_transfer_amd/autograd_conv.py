@@ -19,6 +19,7 @@ class Conv3x3Function(torch.autograd.Function):
         wp = cache.get(key, weight, False)
         y = ops.conv3x3(x, wp, bias.detach() if bias is not None else None, cout, upsample2x, pad_mode, relu)
         ctx.cache, ctx.key = cache, key
+        ctx.compute = "bf16" if wp.dtype == torch.bfloat16 else "f32"   # backward uses the forward's precision
         ctx.upsample2x, ctx.pad_mode, ctx.relu = upsample2x, pad_mode, relu
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -30,7 +31,7 @@ class Conv3x3Function(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wpt = ctx.cache.get(ctx.key, weight, True)
+            wpt = ctx.cache.get(ctx.key, weight, True, ctx.compute)
             dx = ops.conv3x3_dgrad(dy, y, wpt, int(weight.shape[1]), ctx.upsample2x, ctx.pad_mode)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = ops.conv3x3_wgrad(x, dy, y, want_bias=ctx.has_bias, upsample2x=ctx.upsample2x,

@@ -288,6 +288,17 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
+namespace st {
+// Adjoint of the replicate pad (+ upsample) on the padded data gradient; shared with the bf16 path.
+int launch_dgrad_fold(const float* dxp, float* dx, int n, int cin, int h, int w, int up, hipStream_t s) {
+  const int hs = h >> up, ws = w >> up;
+  const long long total = (long long)n * cin * hs * ws;
+  const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 256 * 8);
+  hipLaunchKernelGGL(dgrad_fold_kernel, dim3(blocks), dim3(256), 0, s, dxp, dx, h, w, up, hs, ws, total);
+  return st::check_launch("st_conv3x3_dgrad(fold)");
+}
+}  // namespace st
+
 extern "C" size_t st_conv3x3_packed_elems(int cout, int cin) {
   if (cout <= 0 || cin <= 0) return 0;
   const size_t cin_pad = size_t(st::cdiv(cin, KC)) * KC;
@@ -370,11 +381,5 @@ extern "C" int st_conv3x3_dgrad(const float* dy, const float* y_gate, const floa
   p.pad_zero = 1; p.relu = 0;
   int rc = y_gate ? dispatch_conv<true>(p, s) : dispatch_conv<false>(p, s);
   if (rc != ST_OK || !rep) return rc;
-  const int up = upsample2x ? 1 : 0;
-  const int hs = h >> up, ws = w >> up;
-  const long long total = (long long)n * cin * hs * ws;
-  const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 256 * 8);
-  hipLaunchKernelGGL(dgrad_fold_kernel, dim3(blocks), dim3(256), 0, s, workspace, dx, h, w, up,
-                     hs, ws, total);
-  return st::check_launch("st_conv3x3_dgrad(fold)");
+  return st::launch_dgrad_fold(workspace, dx, n, cin, h, w, upsample2x ? 1 : 0, s);
 }

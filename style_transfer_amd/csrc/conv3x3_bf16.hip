@@ -1,0 +1,381 @@
+// 3x3 stride-1 convolution with bf16 MFMA operands and fp32 accumulation for gfx950 (MI355X):
+// the bf16 compute mode of the encoder / decoder / loss-VGG convolutions (BASELINE config 4,
+// "bf16 compute / fp32 master weights").
+//
+// Same layer semantics as csrc/conv3x3.hip (SymmetricPadding2D((1,1,1,1)) -> Conv2d(3x3) -> ReLU of
+// generator.py:47-76, 89-117, fused nearest x2 upsample of generator.py:92,105,112, zero-padded
+// loss-VGG convs of trainer.py:165-199) and the same boundary: activations are fp32 NCHW in HBM,
+// weights are the fp32 OIHW master copy.  Only the MFMA operands are bf16: activations are rounded
+// (round-to-nearest-even, v_cvt_pk_bf16_f32) while they are staged into LDS, weights when they are
+// packed; products accumulate in fp32 (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate).
+//
+// GEMM view (per image):  D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],  k = (tap, cin).
+//   * M (accumulator registers) = output channels, N (lanes) = 32 consecutive x of one output row:
+//     an accumulator register is an NCHW row segment, stores are full 128-B lines.
+//   * K step of one MFMA = 16 input channels of one tap.  A lane supplies 8 consecutive channels
+//     of its row/column, so both LDS images are channel-innermost: X halo [(TH+2)*34 positions][16 ch]
+//     and W slab [9 taps][BM cout][16 ch], and every operand is ONE conflict-free ds_read_b128
+//     (64 lanes x 16 B contiguous).
+//   * Staging transposes NCHW -> channel-innermost for free: a thread loads the same halo position
+//     of 8 channels (8 coalesced dword loads across the wave), packs them to 8 bf16 and issues one
+//     ds_write_b128.  Edge replicate / zero pad / upsample source index are resolved in the
+//     per-thread offsets computed once; zero padding is a bit mask at the LDS store.
+//   * The weight slab is copied global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs, no
+//     ds_write) into a double buffer: the packed global layout already is the LDS image.
+//   * The next chunk's global loads are issued before the MFMA phase; the activations are
+//     converted and written to LDS after it.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 16;       // input channels per K chunk (one MFMA K step per tap)
+constexpr int TW = 32;       // pixel-tile width == one MFMA N tile
+constexpr int HC = TW + 2;   // halo row length
+constexpr int CPAD = 128;    // packed weights: cout padded to a multiple of this
+constexpr int NTHREADS = 512;   // 8 waves: 2 per SIMD, one block per CU
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+  const float* x;
+  const float* gate;       // GATE kernels: same shape as x; x is read as 0 where gate <= 0
+  const u32x4* wp;         // packed bf16 weights, 16-B units: [chunk][tap][cout_pad][2]
+  const float* bias;
+  float* y;
+  int n, cin, hs, ws;      // source tensor dims
+  int cout, H, W;          // conv-input spatial dims, after the optional upsample
+  int Ho, Wo;              // output dims: (H, W) forward; (H+2, W+2) for the padded data gradient
+  int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
+  int cout_pad, nchunks;
+  int up, pad_zero, relu;
+  int tiles_x, tiles_y;
+};
+
+template <int MT, int NT, int WM, int WP>
+struct Cfg {
+  static constexpr int BM = 32 * MT * WM;
+  static constexpr int TH = NT * WP;
+  static constexpr int HR = TH + 2;
+  static constexpr int PLANE = HR * HC;          // halo positions
+  static constexpr int NITEM = 2 * PLANE;        // (position, channel half) staging items
+  static constexpr int NP = (NITEM + NTHREADS - 1) / NTHREADS;
+  static constexpr int W_UNITS = 9 * BM * 2;     // 16-B units of the weight slab
+  static constexpr int NWI = W_UNITS / 64;        // 1-KiB LDS-DMA wave instructions per weight slab
+  static constexpr int NW = (NWI + 7) / 8;        // ... per wave
+  static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + NITEM) * 16;   // W double-buffered
+};
+
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+  return __builtin_bit_cast(u32x4, b);
+}
+
+// TAIL: cin is not a multiple of 16 (the 3-channel layers): channel indices are clamped per load
+// and the missing channels masked to zero.
+template <int MT, int NT, int WM, int WP, bool GATE, bool TAIL>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p) {
+  using C = Cfg<MT, NT, WM, WP>;
+  static_assert(WM * WP == 8, "eight waves per block");
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+  u32x4* Ws = smem16;                     // 2 x [tap][BM][2]   (filled by LDS-DMA)
+  u32x4* Xs = smem16 + 2 * C::W_UNITS;    // [position][2]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WP, wp = wave % WP;
+
+  int bt = blockIdx.x;
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int b = bt / p.tiles_y;
+  const int m0 = blockIdx.y * C::BM;
+  const int x0 = tx * TW, y0 = ty * C::TH;
+
+  const size_t plane_src = size_t(p.hs) * p.ws;
+  const float* xb = p.x + size_t(b) * p.cin * plane_src;
+  const float* gb = GATE ? p.gate + size_t(b) * p.cin * plane_src : nullptr;
+
+  // ---- per-thread staging items: (halo position, channel half) ---------------------------
+  unsigned soff[C::NP];    // element offset of the item's first channel inside the chunk
+  unsigned smask[C::NP];   // all-ones: keep; 0: zero padding
+  int half_[C::NP];
+#pragma unroll
+  for (int i = 0; i < C::NP; ++i) {
+    const int idx = min(tid + i * NTHREADS, C::NITEM - 1);
+    const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;
+    const int r = pidx / HC, cc = pidx - r * HC;
+    const int gy = y0 + r - 1 - p.shift, gx = x0 + cc - 1 - p.shift;
+    const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+    if (p.up) { cy >>= 1; cx >>= 1; }
+    half_[i] = half;
+    soff[i] = unsigned(cy * p.ws + cx) + (TAIL ? 0u : unsigned(half * 8) * unsigned(plane_src));
+    smask[i] = (inb || !p.pad_zero) ? 0xffffffffu : 0u;
+  }
+
+  float xr[C::NP][8];
+  float gr[GATE ? C::NP : 1][8];
+  // weight slab: wave w copies 1-KiB pieces u = i*8 + w with global_load_lds_dwordx4 (no VGPR
+  // destination); the packed global layout already is the LDS image
+  unsigned woff[C::NW];
+#pragma unroll
+  for (int i = 0; i < C::NW; ++i) {
+    const int e = min(i * 8 + wave, C::NWI - 1) * 64 + lane;
+    const int tap = e / (C::BM * 2), r = e - tap * (C::BM * 2);
+    woff[i] = unsigned(tap) * unsigned(p.cout_pad) * 2u + unsigned(r);
+  }
+
+#define ST_LOAD_CHUNK(chunk_)                                                              \
+  {                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+      if (!TAIL) {                                                                         \
+        const float* src = xb + size_t((chunk_) * KC + j) * plane_src;                     \
+        _Pragma("unroll") for (int i = 0; i < C::NP; ++i) xr[i][j] = src[soff[i]];         \
+        if (GATE) {                                                                        \
+          const float* gsrc = gb + size_t((chunk_) * KC + j) * plane_src;                  \
+          _Pragma("unroll") for (int i = 0; i < C::NP; ++i) gr[i][j] = gsrc[soff[i]];      \
+        }                                                                                  \
+      } else {                                                                             \
+        _Pragma("unroll") for (int i = 0; i < C::NP; ++i) {                                \
+          const int cg = min((chunk_) * KC + half_[i] * 8 + j, p.cin - 1);                 \
+          xr[i][j] = xb[size_t(cg) * plane_src + soff[i]];                                 \
+          if (GATE) gr[i][j] = gb[size_t(cg) * plane_src + soff[i]];                       \
+        }                                                                                  \
+      }                                                                                    \
+    }                                                                                      \
+    const u32x4* wsrc = p.wp + (size_t(chunk_) * 9 * p.cout_pad + m0) * 2;                 \
+    u32x4* wdst = Ws + ((chunk_) & 1) * C::W_UNITS;                                        \
+    _Pragma("unroll") for (int i = 0; i < C::NW; ++i) {                                    \
+      const int u = i * 8 + wave;                                                          \
+      if (C::NWI % 8 == 0 || u < C::NWI)                                                   \
+        __builtin_amdgcn_global_load_lds(                                                  \
+            (const __attribute__((address_space(1))) void*)(wsrc + woff[i]),               \
+            (__attribute__((address_space(3))) void*)(wdst + u * 64), 16, 0, 0);           \
+    }                                                                                      \
+  }
+
+#define ST_STORE_CHUNK(chunk_)                                                             \
+  {                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < C::NP; ++i) {                                    \
+      const int idx = tid + i * NTHREADS;                                                  \
+      float v[8];                                                                          \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                      \
+        unsigned m = smask[i];                                                             \
+        if (TAIL) m &= ((chunk_) * KC + half_[i] * 8 + j) < p.cin ? 0xffffffffu : 0u;      \
+        if (GATE) m &= gr[i][j] > 0.f ? 0xffffffffu : 0u;                                  \
+        v[j] = __uint_as_float(__float_as_uint(xr[i][j]) & m);                             \
+      }                                                                                    \
+      if (C::NITEM % NTHREADS == 0 || idx < C::NITEM) {                                    \
+        const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;                     \
+        Xs[pidx * 2 + half] = pack8(v);                                                    \
+      }                                                                                    \
+    }                                                                                      \
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const u32x4* aPtr = Ws + (wm * (MT * 32) + li) * 2 + lh;
+  const u32x4* bPtr = Xs + ((wp * NT) * HC + li) * 2 + lh;
+
+  ST_LOAD_CHUNK(0);
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    if (chunk) __syncthreads();  // every wave is done reading the previous chunk
+    ST_STORE_CHUNK(chunk);
+    __syncthreads();
+    if (chunk + 1 < p.nchunks) ST_LOAD_CHUNK(chunk + 1);  // in flight during the MFMA phase
+    const u32x4* aP = aPtr + (chunk & 1) * C::W_UNITS;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      bf16x8 a[MT], bb[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        a[mt] = __builtin_bit_cast(bf16x8, aP[(tap * C::BM + mt * 32) * 2]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bb[nt] = __builtin_bit_cast(bf16x8, bPtr[((nt + dy) * HC + dx) * 2]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: bias + ReLU, NCHW store (register r of a tile = one channel row) -----
+  const int xx = x0 + li;
+  if (xx < p.Wo) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < p.cout) {
+          const float bv = p.bias ? p.bias[co] : 0.f;
+          float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.Wo + xx;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int yy = y0 + wp * NT + nt;
+            if (yy < p.Ho) {
+              float v = acc[mt][nt][r] + bv;
+              if (p.relu) v = fmaxf(v, 0.f);
+              yrow[size_t(yy) * p.Wo] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+#undef ST_LOAD_CHUNK
+#undef ST_STORE_CHUNK
+
+// OIHW fp32 -> packed bf16 [cin_pad/16][9][cout_pad][16] (channel innermost: one lane's 8 K values
+// are 16 contiguous bytes).
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
+                                         int O, int I, int flip, int cout, int cin, int cout_pad,
+                                         long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c = int(e % KC);
+    long long k = e / KC;
+    const int o = int(k % cout_pad);
+    k /= cout_pad;
+    const int tap = int(k % 9);
+    const int cg = int(k / 9) * KC + c;
+    float v = 0.f;
+    if (o < cout && cg < cin) {
+      v = flip ? w[(size_t(cg) * I + o) * 9 + (8 - tap)] : w[(size_t(o) * I + cg) * 9 + tap];
+    }
+    wp[e] = (__bf16)v;
+  }
+}
+
+template <int MT, int NT, int WM, int WP, bool GATE>
+int launch_conv(ConvParams& p, hipStream_t stream) {
+  using C = Cfg<MT, NT, WM, WP>;
+  p.tiles_x = st::cdiv(p.Wo, TW);
+  p.tiles_y = st::cdiv(p.Ho, C::TH);
+  const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
+  ST_REQUIRE(ptiles <= 0x7fffffffLL, "st_conv3x3_bf16: too many pixel tiles (%lld)", ptiles);
+  dim3 grid((unsigned)ptiles, (unsigned)st::cdiv(p.cout, C::BM));
+  if (p.cin % KC == 0)
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false>), grid, dim3(NTHREADS),
+                       C::LDS_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, true>), grid, dim3(NTHREADS),
+                       C::LDS_BYTES, stream, p);
+  return st::check_launch("st_conv3x3_bf16");
+}
+
+template <bool GATE>
+int dispatch_conv(ConvParams& p, hipStream_t s) {
+  if (p.cout > 64) return launch_conv<2, 4, 2, 4, GATE>(p, s);   // 128 ch x (16 rows x 32)
+  if (p.cout > 32) {
+    // the gated (data-gradient) form prefetches twice the registers per staging item: use the
+    // 64 ch x (16 rows x 32) tile there so nothing spills
+    if (GATE) return launch_conv<1, 4, 2, 4, GATE>(p, s);
+    return launch_conv<2, 4, 1, 8, GATE>(p, s);                  //  64 ch x (32 rows x 32)
+  }
+  return launch_conv<1, 4, 1, 8, GATE>(p, s);                    //  32 ch x (32 rows x 32)
+}
+
+}  // namespace
+
+namespace st {
+// csrc/conv3x3.hip: adjoint of the replicate pad (+ upsample) on the padded data gradient
+int launch_dgrad_fold(const float* dxp, float* dx, int n, int cin, int h, int w, int up, hipStream_t s);
+}  // namespace st
+
+extern "C" size_t st_conv3x3_packed_elems_bf16(int cout, int cin) {
+  if (cout <= 0 || cin <= 0) return 0;
+  const size_t cin_pad = size_t(st::cdiv(cin, KC)) * KC;
+  const size_t cout_pad = size_t(st::cdiv(cout, CPAD)) * CPAD;
+  return cin_pad * 9 * cout_pad;
+}
+
+extern "C" int st_conv3x3_pack_weights_bf16(const float* w_oihw, void* w_packed, int cout, int cin,
+                                            int transpose_flip, st_stream_t stream) {
+  ST_REQUIRE(w_oihw && w_packed, "st_conv3x3_pack_weights_bf16: null pointer");
+  ST_REQUIRE(cout > 0 && cin > 0, "st_conv3x3_pack_weights_bf16: bad dims cout=%d cin=%d", cout, cin);
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(w_packed) % 16 == 0,
+             "st_conv3x3_pack_weights_bf16: w_packed must be 16-byte aligned");
+  const int pc_out = transpose_flip ? cin : cout;
+  const int pc_in = transpose_flip ? cout : cin;
+  const int cout_pad = st::cdiv(pc_out, CPAD) * CPAD;
+  const long long total = (long long)st_conv3x3_packed_elems_bf16(pc_out, pc_in);
+  const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 4096);
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     w_oihw, (__bf16*)w_packed, cout, cin, transpose_flip ? 1 : 0, pc_out, pc_in,
+                     cout_pad, total);
+  return st::check_launch("st_conv3x3_pack_weights_bf16");
+}
+
+extern "C" int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* y,
+                                   int n, int cin, int hin, int win, int cout, int upsample2x,
+                                   int pad_mode, int relu, st_stream_t stream) {
+  ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
+             "st_conv3x3_fwd_bf16: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO,
+             "st_conv3x3_fwd_bf16: bad pad_mode %d", pad_mode);
+  // per-thread source offsets are 32-bit element offsets that include up to 8 channel planes
+  ST_REQUIRE((long long)hin * win * 16 < (1LL << 31), "st_conv3x3_fwd_bf16: plane too large");
+  ConvParams p;
+  p.x = x; p.gate = nullptr; p.wp = (const u32x4*)w_packed; p.bias = bias; p.y = y;
+  p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
+  p.up = upsample2x ? 1 : 0;
+  p.H = hin << p.up; p.W = win << p.up;
+  p.Ho = p.H; p.Wo = p.W; p.shift = 0;
+  p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
+  p.nchunks = st::cdiv(cin, KC);
+  p.pad_zero = pad_mode == ST_PAD_ZERO;
+  p.relu = relu ? 1 : 0;
+  return dispatch_conv<false>(p, (hipStream_t)stream);
+}
+
+extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t,
+                                     float* dx, float* workspace, int n, int cout, int h, int w,
+                                     int cin, int upsample2x, int pad_mode, st_stream_t stream) {
+  ST_REQUIRE(dy && w_packed_t && dx, "st_conv3x3_dgrad_bf16: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0,
+             "st_conv3x3_dgrad_bf16: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO,
+             "st_conv3x3_dgrad_bf16: bad pad_mode %d", pad_mode);
+  ST_REQUIRE(!upsample2x || (h % 2 == 0 && w % 2 == 0),
+             "st_conv3x3_dgrad_bf16: upsampled layer needs even h, w (got %dx%d)", h, w);
+  ST_REQUIRE(!(upsample2x && pad_mode == ST_PAD_ZERO),
+             "st_conv3x3_dgrad_bf16: upsample2x is only supported with replicate padding");
+  ST_REQUIRE((long long)(h + 2) * (w + 2) * 16 < (1LL << 31), "st_conv3x3_dgrad_bf16: plane too large");
+  const bool rep = pad_mode == ST_PAD_REPLICATE;
+  ST_REQUIRE(!rep || workspace, "st_conv3x3_dgrad_bf16: replicate mode needs a workspace of "
+             "st_conv3x3_dgrad_workspace_bytes()");
+  hipStream_t s = (hipStream_t)stream;
+  ConvParams p;
+  p.x = dy; p.gate = y_gate; p.wp = (const u32x4*)w_packed_t; p.bias = nullptr;
+  p.y = rep ? workspace : dx;
+  p.n = n; p.cin = cout; p.hs = h; p.ws = w; p.cout = cin;
+  p.up = 0; p.H = h; p.W = w;
+  p.Ho = rep ? h + 2 : h; p.Wo = rep ? w + 2 : w; p.shift = rep ? 1 : 0;
+  p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
+  p.nchunks = st::cdiv(cout, KC);
+  p.pad_zero = 1; p.relu = 0;
+  int rc = y_gate ? dispatch_conv<true>(p, s) : dispatch_conv<false>(p, s);
+  if (rc != ST_OK || !rep) return rc;
+  return st::launch_dgrad_fold(workspace, dx, n, cin, h, w, upsample2x ? 1 : 0, s);
+}

@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, precision
 from .autograd import conv3x3_apply, maxpool2x2_apply, conv1x1_apply, sympad_apply
 
 ENCODER_WEIGHTS = r'./src/models/checkpoints/WCT_encoder_decoder/vgg_normalised_conv4_1.pth'   # generator.py:78
@@ -39,12 +39,13 @@ class _PackedWeightCache:
     def __init__(self):
         self._c: Dict[Tuple[int, bool], Tuple[int, int, torch.Tensor]] = {}
 
-    def get(self, key, w: torch.Tensor, transpose_flip: bool = False) -> torch.Tensor:
-        ent = self._c.get((key, transpose_flip))
+    def get(self, key, w: torch.Tensor, transpose_flip: bool = False, compute: Optional[str] = None) -> torch.Tensor:
+        compute = compute or precision.get_compute_dtype()
+        ent = self._c.get((key, transpose_flip, compute))
         if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
             return ent[2]
-        packed = ops.pack_conv3x3_weights(w, transpose_flip)
-        self._c[(key, transpose_flip)] = (w._version, w.data_ptr(), packed)
+        packed = ops.pack_conv3x3_weights(w, transpose_flip, compute)
+        self._c[(key, transpose_flip, compute)] = (w._version, w.data_ptr(), packed)
         return packed
 
     def clear(self):

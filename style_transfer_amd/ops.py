@@ -44,8 +44,11 @@ class _KernelTimer:
 KERNEL_TIMER = _KernelTimer()
 
 
-def conv_kernel_name(cout: int) -> str:
-    """Template instantiation st_conv3x3_fwd dispatches to (csrc/conv3x3.hip)."""
+def conv_kernel_name(cout: int, bf16: bool = False) -> str:
+    """Template instantiation st_conv3x3_fwd[_bf16] dispatches to (csrc/conv3x3.hip, conv3x3_bf16.hip)."""
+    if bf16:
+        return "conv3x3_bf16_kernel<2,4,2,4>" if cout > 64 else (
+            "conv3x3_bf16_kernel<2,4,1,8>" if cout > 32 else "conv3x3_bf16_kernel<1,4,1,8>")
     if cout > 64:
         return "conv3x3_f32_kernel<2,2,2,2>"
     if cout > 32:
@@ -60,13 +63,22 @@ def _pad_code(pad_mode) -> int:
     return _PAD[pad_mode]
 
 
-def pack_conv3x3_weights(w: torch.Tensor, transpose_flip: bool = False) -> torch.Tensor:
-    """OIHW [cout, cin, 3, 3] -> the K-major packed layout st_conv3x3_fwd consumes."""
+def pack_conv3x3_weights(w: torch.Tensor, transpose_flip: bool = False, compute: str = "f32") -> torch.Tensor:
+    """OIHW [cout, cin, 3, 3] -> the packed layout st_conv3x3_fwd consumes: K-major fp32 for
+    ``compute="f32"``, channel-innermost bf16 for ``compute="bf16"`` (the dtype of the returned
+    tensor selects the kernel family in conv3x3 / conv3x3_dgrad)."""
     lib = _lib.load()
     assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3, f"expected OIHW 3x3 weights, got {tuple(w.shape)}"
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = w.detach()
     pc_out, pc_in = (cin, cout) if transpose_flip else (cout, cin)
+    if compute == "bf16":
+        packed = torch.empty(lib.st_conv3x3_packed_elems_bf16(pc_out, pc_in), dtype=torch.bfloat16, device=w.device)
+        _lib.check(lib.st_conv3x3_pack_weights_bf16(_lib.dev_ptr(w, "w"), _lib.dev_ptr(packed, "packed", torch.bfloat16),
+                                                    cout, cin, 1 if transpose_flip else 0, _lib.stream_ptr()),
+                   "st_conv3x3_pack_weights_bf16")
+        return packed
+    assert compute == "f32", f"unknown compute dtype {compute!r}"
     packed = torch.empty(lib.st_conv3x3_packed_elems(pc_out, pc_in), dtype=torch.float32, device=w.device)
     _lib.check(lib.st_conv3x3_pack_weights(_lib.dev_ptr(w, "w"), _lib.dev_ptr(packed, "packed"), cout, cin,
                                            1 if transpose_flip else 0, _lib.stream_ptr()),
@@ -80,18 +92,20 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     lib = _lib.load()
     assert x.dim() == 4, "conv3x3 expects NCHW"
     n, cin, h, w = (int(v) for v in x.shape)
-    need = lib.st_conv3x3_packed_elems(cout, cin)
-    assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} floats, expected {need}"
+    bf16 = w_packed.dtype == torch.bfloat16
+    need = lib.st_conv3x3_packed_elems_bf16(cout, cin) if bf16 else lib.st_conv3x3_packed_elems(cout, cin)
+    assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} elements, expected {need}"
     s = 2 if upsample2x else 1
     y = torch.empty((n, cout, h * s, w * s), dtype=torch.float32, device=x.device)
     ev = None
     if KERNEL_TIMER.enabled:
-        ev = KERNEL_TIMER.record(conv_kernel_name(cout), 2.0 * n * h * s * w * s * cin * cout * 9,
+        ev = KERNEL_TIMER.record(conv_kernel_name(cout, bf16), 2.0 * n * h * s * w * s * cin * cout * 9,
                                  4.0 * (x.numel() + y.numel()))
-    _lib.check(lib.st_conv3x3_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed"),
-                                  _lib.dev_ptr(bias, "bias") if bias is not None else None,
-                                  _lib.dev_ptr(y, "y"), n, cin, h, w, cout, int(upsample2x),
-                                  _pad_code(pad_mode), int(relu), _lib.stream_ptr()), "st_conv3x3_fwd")
+    fn = lib.st_conv3x3_fwd_bf16 if bf16 else lib.st_conv3x3_fwd
+    _lib.check(fn(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
+                  _lib.dev_ptr(bias, "bias") if bias is not None else None,
+                  _lib.dev_ptr(y, "y"), n, cin, h, w, cout, int(upsample2x),
+                  _pad_code(pad_mode), int(relu), _lib.stream_ptr()), "st_conv3x3_fwd")
     if ev is not None:
         ev.record()
     return y
@@ -108,14 +122,16 @@ def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: 
     nbytes = lib.st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, pm)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device) if nbytes else None
     ev = None
+    bf16 = w_packed_t.dtype == torch.bfloat16
     if KERNEL_TIMER.enabled:
-        ev = KERNEL_TIMER.record(conv_kernel_name(cin) + " dgrad", 2.0 * n * h * w * cin * cout * 9,
+        ev = KERNEL_TIMER.record(conv_kernel_name(cin, bf16) + " dgrad", 2.0 * n * h * w * cin * cout * 9,
                                  4.0 * (dy.numel() + dx.numel()))
-    _lib.check(lib.st_conv3x3_dgrad(_lib.dev_ptr(dy, "dy"),
-                                    _lib.dev_ptr(y_gate, "y_gate") if y_gate is not None else None,
-                                    _lib.dev_ptr(w_packed_t, "w_packed_t"), _lib.dev_ptr(dx, "dx"),
-                                    _lib.dev_ptr(ws, "workspace") if ws is not None else None,
-                                    n, cout, h, w, cin, int(upsample2x), pm, _lib.stream_ptr()), "st_conv3x3_dgrad")
+    fn = lib.st_conv3x3_dgrad_bf16 if bf16 else lib.st_conv3x3_dgrad
+    _lib.check(fn(_lib.dev_ptr(dy, "dy"),
+                  _lib.dev_ptr(y_gate, "y_gate") if y_gate is not None else None,
+                  _lib.dev_ptr(w_packed_t, "w_packed_t", w_packed_t.dtype), _lib.dev_ptr(dx, "dx"),
+                  _lib.dev_ptr(ws, "workspace") if ws is not None else None,
+                  n, cout, h, w, cin, int(upsample2x), pm, _lib.stream_ptr()), "st_conv3x3_dgrad")
     if ev is not None:
         ev.record()
     return dx

@@ -1,0 +1,160 @@
+"""GPU parity of the bf16 compute mode (csrc/conv3x3_bf16.hip; BASELINE config 4).
+
+Two bars, both stated here:
+  * against the CPU oracle run with the SAME operand rounding (oracle.ref_ops.conv_compute("bf16"):
+    activations / weights / output gradients rounded to bf16 round-to-nearest-even, fp32 accumulate):
+    1e-3 relative for single layers -- the kernels differ from it only in fp32 accumulation order;
+  * against the fp32 oracle (the reference's numerics): the stated bf16 tolerance is 3e-2 relative L2
+    for the whole 19-conv stylise pipeline and 1e-2 relative (max-norm) for a single layer.
+"""
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+BF16_LAYER_TOL = 1e-2      # one conv layer vs fp32 reference numerics, max-norm relative
+BF16_PIPELINE_TOL = 3e-2   # encoder + AdaIN + decoder vs fp32 reference numerics, relative L2
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from style_transfer_amd import ops as o
+    return o
+
+
+def _ref_conv(x, wt, b, up, pad, relu):
+    xin = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    xp = R.symmetric_pad(xin) if pad == "replicate" else torch.nn.functional.pad(xin, (1, 1, 1, 1))
+    y = R.conv3x3_padded(xp, wt, b)
+    return torch.relu(y) if relu else y
+
+
+CASES = [
+    (1, 16, 32, 8, 8, False, "replicate", True),
+    (2, 3, 64, 37, 45, False, "replicate", True),      # Cin tail (3 of 16 channels), odd sizes
+    (1, 64, 64, 40, 33, False, "replicate", True),
+    (2, 64, 128, 19, 23, False, "replicate", True),
+    (1, 128, 256, 16, 16, False, "zero", True),        # loss-VGG style
+    (1, 256, 256, 9, 11, True, "replicate", True),     # fused nearest x2 upsample
+    (1, 512, 256, 5, 6, False, "replicate", True),
+    (1, 64, 3, 40, 48, False, "replicate", False),     # last decoder conv: no ReLU, Cout=3
+    (1, 20, 130, 7, 70, False, "zero", False),         # ragged channels both ways
+    (1, 16, 40, 1, 1, False, "replicate", True),       # degenerate 1x1 image
+    (1, 128, 128, 64, 96, False, "replicate", True),   # several row tiles per image
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,up,pad,relu", CASES)
+def test_conv3x3_bf16_forward(ops, n, cin, cout, h, w, up, pad, relu):
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    with R.conv_compute("bf16"):
+        ref_emul = _ref_conv(x, wt, b, up, pad, relu)
+    ref_f32 = _ref_conv(x, wt, b, up, pad, relu)
+    wp = ops.pack_conv3x3_weights(wt.cuda(), compute="bf16")
+    assert wp.dtype == torch.bfloat16
+    y = ops.conv3x3(x.cuda(), wp, b.cuda(), cout, upsample2x=up, pad_mode=pad, relu=relu)
+    torch.cuda.synchronize()
+    assert y.shape == ref_emul.shape
+    assert rel_err(y, ref_emul) < 1e-4          # same operand rounding: accumulation order only
+    assert rel_err(y, ref_f32) < BF16_LAYER_TOL
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,up,pad,relu", [c for c in CASES if not (c[5] and c[6] == "zero")])
+def test_conv3x3_bf16_dgrad(ops, n, cin, cout, h, w, up, pad, relu):
+    if up and (h < 1):
+        pytest.skip("n/a")
+    g = torch.Generator().manual_seed(7 + n * 1000 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    with R.conv_compute("bf16"):
+        y_ref = _ref_conv(x, wt, b, up, pad, relu)
+        dy = torch.randn(y_ref.shape, generator=g)
+        (dx_ref,) = torch.autograd.grad(y_ref, x, dy)
+    wp = ops.pack_conv3x3_weights(wt.cuda(), compute="bf16")
+    wpt = ops.pack_conv3x3_weights(wt.cuda(), transpose_flip=True, compute="bf16")
+    y = ops.conv3x3(x.detach().cuda(), wp, b.cuda(), cout, upsample2x=up, pad_mode=pad, relu=relu)
+    dx = ops.conv3x3_dgrad(dy.cuda(), y if relu else None, wpt, cin, up, pad)
+    torch.cuda.synchronize()
+    assert dx.shape == dx_ref.shape
+    # a ReLU gate can flip where the bf16-emulated oracle and the kernel round a pre-activation to
+    # opposite sides of zero (accumulation order); relative L2 is insensitive to isolated flips
+    assert rel_l2(dx, dx_ref) < 2e-3
+
+
+def test_stylize_bf16_pipeline():
+    from style_transfer_amd import precision
+    from style_transfer_amd.generator import Decoder, Encoder
+    from style_transfer_amd.pipeline import stylize
+    from style_transfer_amd.transformer import AdaIN
+    enc_sd, dec_sd = R.make_encoder_state(0), R.make_decoder_state(1)
+    enc = Encoder(weights=enc_sd).cuda().eval()
+    dec = Decoder().cuda().eval()
+    dec.load_state_dict(dec_sd)
+    ada = AdaIN().cuda()
+    g = torch.Generator().manual_seed(11)
+    c = torch.rand(2, 3, 72, 88, generator=g)
+    s = torch.rand(2, 3, 64, 64, generator=g)
+    with precision.compute_dtype("bf16"):
+        out = stylize(enc, dec, ada, c.cuda(), s.cuda(), alpha=1.0)
+    out32 = stylize(enc, dec, ada, c.cuda(), s.cuda(), alpha=1.0)        # same modules, fp32 mode again
+    torch.cuda.synchronize()
+    ref32 = R.stylize(c, s, enc_sd, dec_sd, alpha=1.0)
+    with R.conv_compute("bf16"):
+        ref_emul = R.stylize(c, s, enc_sd, dec_sd, alpha=1.0)
+    assert rel_err(out32, ref32) < 1e-3                   # the packed-weight cache did not mix precisions
+    assert rel_l2(out, ref32) < BF16_PIPELINE_TOL         # stated bf16 tolerance vs the reference numerics
+    # vs the same-rounding oracle: a 1e-7 accumulation-order difference moves an activation that sits on a
+    # bf16 rounding boundary by a whole bf16 ulp (2^-9) in the next layer's operand, so 19 layers deep the two
+    # agree to a small multiple of the bf16 ulp, not to fp32 accuracy (single layers agree to 1e-4, above)
+    assert rel_l2(out, ref_emul) < 1.5e-2
+
+
+def test_train_step_bf16_close_to_fp32():
+    """Training step in bf16 compute mode vs the fp32 HIP path: every loss within 3e-2 relative; the decoder
+    gradients of the content, style and variation terms aligned (cosine > 0.98).  The histogram term's gradient is
+    not compared: with random decoder weights ~96 % of the normalised decoded pixels sit outside the [0,1] clamp
+    of losses.py:170, the gradient mask is discontinuous there, and a bf16-sized perturbation of the decoded
+    image re-draws it (the fp32 test already needs 6e-2 for that term, tests/test_gpu_train.py)."""
+    from style_transfer_amd import precision
+    from test_gpu_train import _build
+    step, *_ = _build(False, [21], [2, 7, 14, 19, 25], 0.1)
+    g = torch.Generator().manual_seed(5)
+    content = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    style = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    params = list(step.decoder.named_parameters())
+
+    def run(i):
+        for _, p in params + list(step.transformer.named_parameters()):
+            p.grad = None
+        losses = step.forward_losses(content, style)
+        losses[i].backward()
+        return [float(l.detach()) for l in losses], [p.grad.clone() for _, p in params]
+
+    for i, name in enumerate(["content", "style", "variation"]):
+        l32, g32 = run(i)
+        with precision.compute_dtype("bf16"):
+            l16, g16 = run(i)
+        for a, b in zip(l16, l32):
+            assert abs(a - b) <= 3e-2 * max(abs(b), 1e-3), name
+        for (pname, _), a, b in zip(params, g16, g32):
+            assert torch.isfinite(a).all()
+            if name == "variation" and pname.endswith("28.bias"):
+                continue                                     # analytically zero
+            cos = float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-30))
+            assert cos > 0.98, (name, pname, cos)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Per-layer timing of the fp32 MFMA conv3x3 kernel on the encoder/decoder shapes
+"""Per-layer timing of the fp32 / bf16 MFMA conv3x3 kernels on the encoder/decoder shapes
 (BASELINE configs[1]: batch 16 at 512x512).  HIP events on the launch stream.
 
-    python tools/bench_conv_layers.py [--batch 16] [--side 512] [--iters 5]
+    python tools/bench_conv_layers.py [--batch 16] [--side 512] [--iters 5] [--mode fwd|dgrad|wgrad] [--compute f32|bf16]
 """
 import argparse
 import os
@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "wgrad"])
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16"])
     args = ap.parse_args()
     dev = torch.device("cuda")
     tot_t = tot_f = 0.0
@@ -39,10 +40,10 @@ def main():
         x = torch.randn(args.batch, cin, h, h, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         b = torch.randn(cout, device=dev)
-        wp = ops.pack_conv3x3_weights(w)
+        wp = ops.pack_conv3x3_weights(w, compute=args.compute)
         y = ops.conv3x3(x, wp, b, cout, upsample2x=up)
         dy = torch.randn_like(y)
-        wpt = ops.pack_conv3x3_weights(w, transpose_flip=True)
+        wpt = ops.pack_conv3x3_weights(w, transpose_flip=True, compute=args.compute)
         if args.mode == "fwd":
             fn = lambda: ops.conv3x3(x, wp, b, cout, upsample2x=up)
         elif args.mode == "dgrad":
