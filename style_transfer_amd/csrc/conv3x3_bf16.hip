@@ -22,9 +22,10 @@
 //     per-thread offsets computed once; zero padding is a bit mask at the LDS store.
 //   * The weight slab is copied global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs, no
 //     ds_write) into a double buffer: the packed global layout already is the LDS image.
-//   * The next chunk's global loads are issued before the MFMA phase; the activations are
-//     converted and written to LDS after it.
+//   * Both LDS images are double-buffered, one workgroup barrier per chunk; the two waves of a
+//     SIMD run staging and MFMA phases in opposite order (see the schedule comment in the kernel).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -52,7 +53,8 @@ struct ConvParams {
   int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
   int up, pad_zero, relu;
-  int tiles_x, tiles_y;
+  int tiles_x, tiles_y, ctiles, xcd_swizzle;
+  int ablate;              // debug only (ST_BF16_ABLATE): 1 skip MFMA, 2 skip X staging, 4 skip W DMA
 };
 
 template <int MT, int NT, int WM, int WP>
@@ -66,7 +68,7 @@ struct Cfg {
   static constexpr int W_UNITS = 9 * BM * 2;     // 16-B units of the weight slab
   static constexpr int NWI = W_UNITS / 64;        // 1-KiB LDS-DMA wave instructions per weight slab
   static constexpr int NW = (NWI + 7) / 8;        // ... per wave
-  static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + NITEM) * 16;   // W double-buffered
+  static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + 2 * NITEM) * 16;   // both double-buffered
 };
 
 __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
@@ -84,19 +86,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   static_assert(WM * WP == 8, "eight waves per block");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   u32x4* Ws = smem16;                     // 2 x [tap][BM][2]   (filled by LDS-DMA)
-  u32x4* Xs = smem16 + 2 * C::W_UNITS;    // [position][2]
+  u32x4* Xs = smem16 + 2 * C::W_UNITS;    // 2 x [position][2]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WP, wp = wave % WP;
 
-  int bt = blockIdx.x;
+  // Block -> (pixel tile, channel tile).  Blocks are dealt round-robin over the 8 XCDs (each with
+  // its own L2), so ids that differ by 8 share an XCD: the channel tiles of one pixel tile get
+  // consecutive slots on ONE XCD and the 2..4 reads of the same activation tile hit its L2.
+  int bt, ct;
+  {
+    const int id = blockIdx.x;
+    if (p.xcd_swizzle) {
+      const int k = id >> 3;
+      ct = k % p.ctiles;
+      bt = (k / p.ctiles) * 8 + (id & 7);
+    } else {
+      ct = id % p.ctiles;
+      bt = id / p.ctiles;
+    }
+  }
   const int tx = bt % p.tiles_x;
   bt /= p.tiles_x;
   const int ty = bt % p.tiles_y;
   const int b = bt / p.tiles_y;
-  const int m0 = blockIdx.y * C::BM;
+  const int m0 = ct * C::BM;
   const int x0 = tx * TW, y0 = ty * C::TH;
 
   const size_t plane_src = size_t(p.hs) * p.ws;
@@ -123,6 +139,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 
   float xr[C::NP][8];
   float gr[GATE ? C::NP : 1][8];
+  constexpr int NLOADS = C::NP * 8 * (GATE ? 2 : 1);   // dword loads per thread per chunk
   // weight slab: wave w copies 1-KiB pieces u = i*8 + w with global_load_lds_dwordx4 (no VGPR
   // destination); the packed global layout already is the LDS image
   unsigned woff[C::NW];
@@ -133,7 +150,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     woff[i] = unsigned(tap) * unsigned(p.cout_pad) * 2u + unsigned(r);
   }
 
-#define ST_LOAD_CHUNK(chunk_)                                                              \
+  // ---- staging macros ----------------------------------------------------------------------
+  // weights of chunk_ -> W buffer (chunk_ & 1) by LDS-DMA
+#define ST_ISSUE_W(chunk_)                                                                 \
+  {                                                                                        \
+    const u32x4* wsrc = p.wp + (size_t(chunk_) * 9 * p.cout_pad + m0) * 2;                 \
+    u32x4* wdst = Ws + ((chunk_) & 1) * C::W_UNITS;                                        \
+    _Pragma("unroll") for (int i = 0; i < C::NW; ++i) {                                    \
+      const int u = i * 8 + wave;                                                          \
+      if (C::NWI % 8 == 0 || u < C::NWI)                                                   \
+        __builtin_amdgcn_global_load_lds(                                                  \
+            (const __attribute__((address_space(1))) void*)(wsrc + woff[i]),               \
+            (__attribute__((address_space(3))) void*)(wdst + u * 64), 16, 0, 0);           \
+    }                                                                                      \
+  }
+
+  // activations of chunk_ -> registers (exactly NLOADS dword loads per thread)
+#define ST_LOAD_X(chunk_)                                                                  \
   {                                                                                        \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
       if (!TAIL) {                                                                         \
@@ -151,19 +184,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         }                                                                                  \
       }                                                                                    \
     }                                                                                      \
-    const u32x4* wsrc = p.wp + (size_t(chunk_) * 9 * p.cout_pad + m0) * 2;                 \
-    u32x4* wdst = Ws + ((chunk_) & 1) * C::W_UNITS;                                        \
-    _Pragma("unroll") for (int i = 0; i < C::NW; ++i) {                                    \
-      const int u = i * 8 + wave;                                                          \
-      if (C::NWI % 8 == 0 || u < C::NWI)                                                   \
-        __builtin_amdgcn_global_load_lds(                                                  \
-            (const __attribute__((address_space(1))) void*)(wsrc + woff[i]),               \
-            (__attribute__((address_space(3))) void*)(wdst + u * 64), 16, 0, 0);           \
-    }                                                                                      \
   }
 
-#define ST_STORE_CHUNK(chunk_)                                                             \
+  // registers -> bf16 -> X buffer (chunk_ & 1)
+#define ST_STORE_X(chunk_)                                                                 \
   {                                                                                        \
+    u32x4* xdst = Xs + ((chunk_) & 1) * C::NITEM;                                          \
     _Pragma("unroll") for (int i = 0; i < C::NP; ++i) {                                    \
       const int idx = tid + i * NTHREADS;                                                  \
       float v[8];                                                                          \
@@ -175,10 +201,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       }                                                                                    \
       if (C::NITEM % NTHREADS == 0 || idx < C::NITEM) {                                    \
         const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;                     \
-        Xs[pidx * 2 + half] = pack8(v);                                                    \
+        xdst[pidx * 2 + half] = pack8(v);                                                  \
       }                                                                                    \
     }                                                                                      \
   }
+
+  // 9 taps x MT x NT MFMAs on chunk_'s buffers
+#define ST_MFMA(chunk_)                                                                    \
+  {                                                                                        \
+    const u32x4* aP = aPtr + ((chunk_) & 1) * C::W_UNITS;                                  \
+    const u32x4* bP = bPtr + ((chunk_) & 1) * C::NITEM;                                    \
+    _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                  \
+      const int dy = tap / 3, dx = tap % 3;                                                \
+      bf16x8 a[MT], bb[NT];                                                                \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                    \
+          a[mt] = __builtin_bit_cast(bf16x8, aP[(tap * C::BM + mt * 32) * 2]);             \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+          bb[nt] = __builtin_bit_cast(bf16x8, bP[((nt + dy) * HC + dx) * 2]);              \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                    \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bb[nt], acc[mt][nt], \
+                                                                0, 0, 0);                  \
+    }                                                                                      \
+  }
+
+  // Workgroup barrier that does NOT drain the register loads issued after the LDS-DMA pieces:
+  // vmcnt is in order, so allowing the NLOADS youngest operations to stay in flight still
+  // retires every older LDS-DMA (the counter saturates at 63: a larger NLOADS only waits for a
+  // few of the oldest register loads as well); lgkmcnt(0) retires this wave's ds_writes.  The "memory" clobber
+  // keeps the compiler from moving LDS accesses across it.
+#define ST_BARRIER_KEEP_LOADS()                                                            \
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NLOADS < 63 ? NLOADS : 63) : "memory")
+#define ST_BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -191,29 +245,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   const u32x4* aPtr = Ws + (wm * (MT * 32) + li) * 2 + lh;
   const u32x4* bPtr = Xs + ((wp * NT) * HC + li) * 2 + lh;
 
-  ST_LOAD_CHUNK(0);
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    if (chunk) __syncthreads();  // every wave is done reading the previous chunk
-    ST_STORE_CHUNK(chunk);
-    __syncthreads();
-    if (chunk + 1 < p.nchunks) ST_LOAD_CHUNK(chunk + 1);  // in flight during the MFMA phase
-    const u32x4* aP = aPtr + (chunk & 1) * C::W_UNITS;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      bf16x8 a[MT], bb[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        a[mt] = __builtin_bit_cast(bf16x8, aP[(tap * C::BM + mt * 32) * 2]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        bb[nt] = __builtin_bit_cast(bf16x8, bPtr[((nt + dy) * HC + dx) * 2]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+  // Schedule (X and W double-buffered in LDS, ONE barrier per chunk).  In iteration c every wave
+  // issues the LDS-DMA of W(c+1), converts/stores X(c+1) from the registers loaded one iteration
+  // earlier, issues the register loads of X(c+2) and runs the MFMAs of chunk c.  The two waves
+  // that share a SIMD do these in opposite order (waves 0-3 stage first, waves 4-7 compute
+  // first), so one wave's staging runs under its partner's MFMAs instead of both idling the
+  // matrix pipe together.
+  const bool lead = __builtin_amdgcn_readfirstlane(wave) < 4;
+  const int nch = p.nchunks;
+  ST_ISSUE_W(0);
+  ST_LOAD_X(0);
+  ST_STORE_X(0);
+  if (nch > 1) ST_LOAD_X(1);
+  ST_BARRIER_DRAIN();
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const bool more1 = chunk + 1 < nch, more2 = chunk + 2 < nch;
+    if (more1 && !(p.ablate & 4)) ST_ISSUE_W(chunk + 1);
+    asm volatile("" ::: "memory");   // keep the LDS-DMA ahead of the register loads (vmcnt order)
+    if (lead && !(p.ablate & 2)) {
+      if (more1) ST_STORE_X(chunk + 1);
+      if (more2) ST_LOAD_X(chunk + 2);
     }
+    if (!(p.ablate & 1)) ST_MFMA(chunk);
+    if (!lead && !(p.ablate & 2)) {
+      if (more1) ST_STORE_X(chunk + 1);
+      if (more2) ST_LOAD_X(chunk + 2);
+    }
+    if (more2) { ST_BARRIER_KEEP_LOADS(); } else { ST_BARRIER_DRAIN(); }
   }
 
   // ---- epilogue: bias + ReLU, NCHW store (register r of a tile = one channel row) -----
@@ -242,8 +300,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   }
 }
 
-#undef ST_LOAD_CHUNK
-#undef ST_STORE_CHUNK
+#undef ST_ISSUE_W
+#undef ST_LOAD_X
+#undef ST_STORE_X
+#undef ST_MFMA
+#undef ST_BARRIER_KEEP_LOADS
+#undef ST_BARRIER_DRAIN
 
 // OIHW fp32 -> packed bf16 [cin_pad/16][9][cout_pad][16] (channel innermost: one lane's 8 K values
 // are 16 contiguous bytes).
@@ -271,9 +333,12 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   using C = Cfg<MT, NT, WM, WP>;
   p.tiles_x = st::cdiv(p.Wo, TW);
   p.tiles_y = st::cdiv(p.Ho, C::TH);
+  { const char* e = getenv("ST_BF16_ABLATE"); p.ablate = e ? atoi(e) : 0; }
   const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
-  ST_REQUIRE(ptiles <= 0x7fffffffLL, "st_conv3x3_bf16: too many pixel tiles (%lld)", ptiles);
-  dim3 grid((unsigned)ptiles, (unsigned)st::cdiv(p.cout, C::BM));
+  p.ctiles = st::cdiv(p.cout, C::BM);
+  ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3_bf16: too many tiles (%lld)", ptiles * p.ctiles);
+  p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
+  dim3 grid((unsigned)(ptiles * p.ctiles));
   if (p.cin % KC == 0)
     hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false>), grid, dim3(NTHREADS),
                        C::LDS_BYTES, stream, p);
@@ -289,8 +354,8 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
   if (p.cout > 32) {
     // the gated (data-gradient) form prefetches twice the registers per staging item: use the
     // 64 ch x (16 rows x 32) tile there so nothing spills
-    if (GATE) return launch_conv<1, 4, 2, 4, GATE>(p, s);
-    return launch_conv<2, 4, 1, 8, GATE>(p, s);                  //  64 ch x (32 rows x 32)
+    if constexpr (GATE) return launch_conv<1, 4, 2, 4, GATE>(p, s);
+    else return launch_conv<2, 4, 1, 8, GATE>(p, s);             //  64 ch x (32 rows x 32)
   }
   return launch_conv<1, 4, 1, 8, GATE>(p, s);                    //  32 ch x (32 rows x 32)
 }
