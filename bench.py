@@ -42,10 +42,13 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PREWARM_SECONDS = float(os.environ.get("ST_BENCH_PREWARM", "1.0"))
 BATCH, SIDE = 16, 512           # configs[1]
 TRAIN_BATCH, TRAIN_SIDE = 8, 256  # configs[2]
 CONTENT_IDX, STYLE_IDX = [21], [2, 7, 14, 19, 25]   # CLI defaults, train.py:80-83
 DOMINANT = "conv3x3_f32_kernel<2,2,2,2>"
+DOMINANT_BF16 = "conv3x3_bf16_kernel<2,4,2,4>"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 # HBM bytes per launch of the dominant kernel from profiles/r1_bench_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
 # KiB, averaged over its 20 launches per inference step; 4-B-per-lane loads: FETCH_SIZE taken as reported)
 DOMINANT_TRAFFIC_BYTES = (833662.017 + 298188.8) * 1024
@@ -171,11 +174,21 @@ class Ctx:
 
 def timed(ctx: Ctx, fn, steps: int, warmup: int, collect_kernels: bool):
     from style_transfer_amd import ops
+    # clock / allocator pre-warm (not a step: a fresh box runs its first ~1 s about 4 % slow), then W warmup steps
+    t_end = time.perf_counter() + PREWARM_SECONDS
+    while time.perf_counter() < t_end:
+        fn()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     ctx.barrier()
+    collect_kernels = collect_kernels and not os.environ.get("ST_NO_KTIMER")
     if collect_kernels:
         ops.KERNEL_TIMER.start()
+        fn()                                             # untimed: count the launches of one step
+        per_step = len(ops.KERNEL_TIMER.stop())
+        ctx.barrier()
+        ops.KERNEL_TIMER.start(prealloc=per_step * steps)   # events created outside the timed region
     t0 = time.perf_counter()
     for _ in range(steps):
         out = fn()
@@ -185,7 +198,7 @@ def timed(ctx: Ctx, fn, steps: int, warmup: int, collect_kernels: bool):
     return ctx.max_over_ranks(elapsed), records, out
 
 
-def run_inference(ctx: Ctx, args):
+def run_inference(ctx: Ctx, args, compute: str = "f32"):
     from oracle import ref_ops as R     # seeded synthetic weights only
     from style_transfer_amd.generator import Decoder, Encoder
     from style_transfer_amd.pipeline import stylize
@@ -200,13 +213,32 @@ def run_inference(ctx: Ctx, args):
     content = torch.rand(args.batch, 3, args.side, args.side, generator=g).to(dev)   # resident in HBM
     style = torch.rand(args.batch, 3, args.side, args.side, generator=g).to(dev)
 
-    elapsed, records, out = timed(ctx, lambda: stylize(enc, dec, ada, content, style, alpha=1.0),
-                                  args.steps, args.warmup, collect_kernels=True)
+    from style_transfer_amd import precision
+    with precision.compute_dtype(compute):
+        elapsed, records, out = timed(ctx, lambda: stylize(enc, dec, ada, content, style, alpha=1.0),
+                                      args.steps, args.warmup, collect_kernels=True)
     assert torch.isfinite(out).all()
     value = ctx.world * args.batch * args.steps / elapsed
     e_f, d_f = encoder_decoder_flops(args.side)
     per_img = 2 * e_f + d_f
 
+    if compute == "bf16":
+        allconv = [r for r in records if r["kernel"].startswith("conv3x3_bf16_kernel")]
+        dom = [r for r in allconv if r["kernel"] == DOMINANT_BF16]
+        fl, sec = sum(r["flops"] for r in dom), sum(r["ms"] for r in dom) * 1e-3
+        ach = fl / sec / 1e12 if sec > 0 else 0.0
+        return {"metric": "stylized 512x512 img/s (inference)", "value": round(value, 3), "unit": "img/s",
+                "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "dtype": "bf16",
+                "config": {"workload": f"inference batch {args.batch} at {args.side}x{args.side} per GPU, bf16 MFMA "
+                                       "operands / fp32 accumulate / fp32 NCHW activations", "batch_per_gpu": args.batch,
+                           "side": args.side},
+                "model_tflops": round(value * per_img / 1e12, 2),
+                "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": DOMINANT_BF16,
+                             "launches": len(dom), "avg_launch_us": round(sec / max(1, len(dom)) * 1e6, 2),
+                             "all_conv_tflops": round(sum(r["flops"] for r in allconv) /
+                                                      max(1e-12, sum(r["ms"] for r in allconv) * 1e-3) / 1e12, 1)}}
     dom = [r for r in records if r["kernel"] == DOMINANT]
     allconv = [r for r in records if r["kernel"].startswith("conv3x3_f32_kernel")]
     flops = sum(r["flops"] for r in dom)
@@ -250,7 +282,7 @@ def run_inference(ctx: Ctx, args):
     }
 
 
-def run_train(ctx: Ctx, args, use_vincent: bool):
+def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: int = None, side: int = None):
     from oracle import ref_ops as R     # seeded synthetic weights only
     from style_transfer_amd.trainer import GradBucket, Trainer
 
@@ -270,27 +302,31 @@ def run_train(ctx: Ctx, args, use_vincent: bool):
         step = tr.make_step(encoder, decoder, transformer, loss_vgg)
     bucket = GradBucket(params)
     g = torch.Generator().manual_seed(4321 + ctx.rank)
-    s = args.train_side
-    content = torch.rand(args.train_batch, 3, s, s, generator=g).to(dev)
-    style = torch.rand(args.train_batch, 3, s, s, generator=g).to(dev)
+    s = side or args.train_side
+    tb = batch or args.train_batch
+    content = torch.rand(tb, 3, s, s, generator=g).to(dev)
+    style = torch.rand(tb, 3, s, s, generator=g).to(dev)
 
     def one():
         return tr.optimize_step(step, opt, bucket, content, style)
 
+    from style_transfer_amd import precision
     steps, warmup = args.train_steps, args.train_warmup
-    elapsed, _, losses = timed(ctx, one, steps, warmup, collect_kernels=False)
+    with precision.compute_dtype(compute):
+        elapsed, _, losses = timed(ctx, one, steps, warmup, collect_kernels=False)
     total = float(losses[4].detach())
     assert total == total, "training loss is NaN"
-    value = ctx.world * args.train_batch * steps / elapsed
+    value = ctx.world * tb * steps / elapsed
     per_img = train_flops_per_image(s)
     return {"metric": "train img/s", "value": round(value, 3), "unit": "img/s", "n_gpus": ctx.world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "scaling": "weak",
-            "dtype": "f32", "style_loss": "VincentStyleLoss (covariance MFMA + eigh)" if use_vincent
+            "dtype": compute, "style_loss": "VincentStyleLoss (covariance MFMA + eigh)" if use_vincent
             else "AdaINStyleLoss (mean/std)",
-            "config": {"workload": f"BASELINE configs[2]: training step batch {args.train_batch} at {s}x{s} fp32 per "
+            "config": {"workload": ("BASELINE configs[2]: " if (compute, tb, s) == ("f32", 8, 256) else "") +
+                                   f"training step batch {tb} at {s}x{s} {compute} per "
                                    "GPU: 2x encoder, AdaIN, decoder, Normalize, loss VGG19 (idx 21 / 2,7,14,19,25), "
                                    "content + style + TV + RGB-uv histogram losses, backward, Adam(decoder + eps)",
-                       "batch_per_gpu": args.train_batch, "side": s,
+                       "batch_per_gpu": tb, "side": s,
                        "parallelism": f"dp{ctx.world}: batch sharded, one 14.02 MB fp32 RCCL all-reduce + 2 scalar "
                                       "all-reduces per step" if ctx.world > 1 else "single GPU",
                        "gflop_per_image_necessary": round(per_img / 1e9, 2)},
@@ -311,6 +347,7 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--no-gram", action="store_true", help="skip the VincentStyleLoss variant of the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 compute-mode legs (BASELINE configs[3] shape)")
     args = ap.parse_args()
 
     ctx = Ctx()
@@ -326,6 +363,15 @@ def main():
             train = None
         if train is not None:
             line["train"] = train
+    if not args.no_bf16:
+        # BASELINE configs[3] per-GPU shape (batch 64 over 8 GPUs = 8 per GPU at 512x512, bf16 compute)
+        bf = {}
+        if args.mode in ("both", "infer"):
+            bf["inference"] = run_inference(ctx, args, compute="bf16")
+        if args.mode in ("both", "train"):
+            bf["train"] = run_train(ctx, args, use_vincent=False, compute="bf16", batch=8, side=512)
+            bf["train"]["config"]["workload"] = "BASELINE configs[3] per-GPU shape: " + bf["train"]["config"]["workload"]
+        line["bf16"] = bf
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline:
             if args.mode in ("both", "infer"):

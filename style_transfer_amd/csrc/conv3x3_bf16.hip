@@ -25,6 +25,7 @@
 //   * Both LDS images are double-buffered, one workgroup barrier per chunk; the two waves of a
 //     SIMD run staging and MFMA phases in opposite order (see the schedule comment in the kernel).
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "common.h"
@@ -40,6 +41,7 @@ constexpr int NTHREADS = 512;   // 8 waves: 2 per SIMD, one block per CU
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
   const float* x;
@@ -54,6 +56,7 @@ struct ConvParams {
   int cout_pad, nchunks;
   int up, pad_zero, relu;
   int tiles_x, tiles_y, ctiles, xcd_swizzle;
+  int vec_store;           // Wo % 4 == 0 and y 16-B aligned: 16-B-per-lane epilogue stores
   int ablate;              // debug only (ST_BF16_ABLATE): 1 skip MFMA, 2 skip X staging, 4 skip W DMA
 };
 
@@ -274,24 +277,62 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     if (more2) { ST_BARRIER_KEEP_LOADS(); } else { ST_BARRIER_DRAIN(); }
   }
 
-  // ---- epilogue: bias + ReLU, NCHW store (register r of a tile = one channel row) -----
-  const int xx = x0 + li;
-  if (xx < p.Wo) {
+  // ---- epilogue: bias + ReLU, NCHW store ---------------------------------------------------
+  // An accumulator register is 32 consecutive x of one channel row (one dword per lane).  Stored
+  // as-is that is 16 dword-store instructions per 32x32 tile, and a block with the CU to itself
+  // becomes store-ISSUE-bound.  Each wave therefore transposes a tile through a private 4 KB LDS
+  // patch (the staging buffers are free after the last barrier) and writes 16 B per lane: 8 lanes
+  // cover one 128-B row segment, a wave instruction writes 8 channel rows.
+  if (p.vec_store) {
+    float* patch = reinterpret_cast<float*>(smem16) + wave * (32 * 32);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      const int cbase = m0 + wm * (MT * 32) + mt * 32;
+      float bv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < p.cout) {
-          const float bv = p.bias ? p.bias[co] : 0.f;
-          float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.Wo + xx;
+        const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bv[r] = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+      }
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int yy = y0 + wp * NT + nt;
-            if (yy < p.Ho) {
-              float v = acc[mt][nt][r] + bv;
-              if (p.relu) v = fmaxf(v, 0.f);
-              yrow[size_t(yy) * p.Wo] = v;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int yy = y0 + wp * NT + nt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[mt][nt][r] + bv[r];
+          if (p.relu) v = fmaxf(v, 0.f);
+          patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int idx = q * 64 + lane;
+          const int ch = idx >> 3, x4 = (idx & 7) * 4;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ch * 32 + x4);
+          const int co = cbase + ch, xs = x0 + x4;
+          if (co < p.cout && yy < p.Ho && xs < p.Wo)
+            *reinterpret_cast<f32x4*>(p.y + ((size_t(b) * p.cout + co) * p.Ho + yy) * p.Wo + xs) = v;
+        }
+      }
+    }
+  } else {
+    const int xx = x0 + li;
+    if (xx < p.Wo) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < p.cout) {
+            const float bv = p.bias ? p.bias[co] : 0.f;
+            float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.Wo + xx;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int yy = y0 + wp * NT + nt;
+              if (yy < p.Ho) {
+                float v = acc[mt][nt][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                yrow[size_t(yy) * p.Wo] = v;
+              }
             }
           }
         }
@@ -338,6 +379,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   p.ctiles = st::cdiv(p.cout, C::BM);
   ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3_bf16: too many tiles (%lld)", ptiles * p.ctiles);
   p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
+  p.vec_store = (p.Wo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
   dim3 grid((unsigned)(ptiles * p.ctiles));
   if (p.cin % KC == 0)
     hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false>), grid, dim3(NTHREADS),

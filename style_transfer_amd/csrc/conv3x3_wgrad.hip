@@ -245,8 +245,10 @@ Plan make_plan(int n, int cout, int cin, int H, int W) {
   const long long nt = (long long)n * pl.tiles_x * pl.tiles_y;
   pl.ntiles = (int)std::min<long long>(nt, 0x7fffffff);
   const int ctiles = st::cdiv(cin, CI) * st::cdiv(cout, BO);
-  // aim for ~4 blocks per CU (2 resident), but keep >= 4 pixel tiles per block
-  int want = std::max(1, (256 * 4) / ctiles);   // ~2 resident blocks per CU, two waves of them
+  // one block per CU, exactly one round of blocks: measured on MI355X (B = 8, 256^2 and 512^2 decoder
+  // shapes) 256 blocks 6.1 ms, 512 blocks 6.8, 1024 blocks 7.9, 384 blocks 8.2 (ragged second round);
+  // fewer splits also means fewer partial slabs to write and re-read
+  int want = std::max(1, 256 / ctiles);
   int nsplit = std::max(1, std::min(want, pl.ntiles / 4));
   nsplit = std::min(nsplit, 512);
   pl.tiles_per_split = st::cdiv(pl.ntiles, nsplit);

@@ -162,27 +162,32 @@ __global__ __launch_bounds__(NT) void hist_accum_kernel(const float* __restrict_
 }
 
 // ---- finalize: sum slabs, normalise ------------------------------------------------------------
-__global__ __launch_bounds__(NT) void hist_finalize_kernel(const float* __restrict__ slabs, int nsplit,
-                                                          int B, float* __restrict__ hist,
-                                                          float* __restrict__ totals) {
+// Stage 1 (grid E/NT x B): one element per thread, fixed-order sum over the split slabs (coalesced
+// across the block), un-normalised value -> hist, per-block partial total -> part[b][blockIdx.x].
+// Stage 2 (same grid): image total = fixed-order sum of its E/NT partials, then the true division of
+// losses.py:319-320.  Deterministic; bins stay exact integers in thresholding mode.
+constexpr int HIST_E = 3 * HB * HB;
+constexpr int HIST_PARTS = HIST_E / NT;
+
+__global__ __launch_bounds__(NT) void hist_sum_slabs_kernel(const float* __restrict__ slabs, int nsplit, int B,
+                                                           float* __restrict__ hist, float* __restrict__ part) {
   __shared__ float red[NT / 64];
-  constexpr int E = 3 * HB * HB, PER = E / NT;
-  const int b = blockIdx.x;
-  float v[PER];
-  float s = 0.f;
-#pragma unroll 4
-  for (int k = 0; k < PER; ++k) {
-    const int e = threadIdx.x + k * NT;
-    float t = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) t += slabs[((size_t)sp * B + b) * E + e];
-    v[k] = t;
-    s += t;
-  }
-  const float total = st::block_sum<NT>(s, red);
-  const float den = total + EPSF;   // losses.py:319-320 (a true division: bit-identical to the reference)
-#pragma unroll 4
-  for (int k = 0; k < PER; ++k) hist[(size_t)b * E + threadIdx.x + k * NT] = v[k] / den;
-  if (threadIdx.x == 0) totals[b] = total;
+  const int b = blockIdx.y, e = blockIdx.x * NT + threadIdx.x;
+  float t = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) t += slabs[((size_t)sp * B + b) * HIST_E + e];
+  hist[(size_t)b * HIST_E + e] = t;
+  const float s = st::block_sum<NT>(t, red);
+  if (threadIdx.x == 0) part[b * HIST_PARTS + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(NT) void hist_normalize_kernel(float* __restrict__ hist, const float* __restrict__ part,
+                                                           float* __restrict__ totals) {
+  const int b = blockIdx.y, e = blockIdx.x * NT + threadIdx.x;
+  float total = 0.f;
+  for (int k = 0; k < HIST_PARTS; ++k) total += part[b * HIST_PARTS + k];   // same order in every thread
+  const float den = total + EPSF;   // losses.py:319-320 (a true division, like the reference)
+  hist[(size_t)b * HIST_E + e] = hist[(size_t)b * HIST_E + e] / den;
+  if (blockIdx.x == 0 && threadIdx.x == 0) totals[b] = total;
 }
 
 // ---- Hellinger pieces --------------------------------------------------------------------------
@@ -438,6 +443,9 @@ Geo geometry(int n, int h, int w, int insz) {
   return g;
 }
 
+// floats of the pixel-record region (its head doubles as the finalize partial-total buffer)
+size_t rec_elems(int n, int N) { return std::max(size_t(n) * NREC * N, size_t(n) * HIST_PARTS); }
+
 int fill_params(HistParams& hp, int method, float sigma, const double* bins_host, int nbins,
                 int intensity_scale, const char* who) {
   ST_REQUIRE(bins_host, "%s: null bins", who);
@@ -461,7 +469,7 @@ extern "C" size_t st_rgbuv_hist_workspace_bytes(int n, int h, int w, int insz) {
   if (n <= 0 || h <= 0 || w <= 0 || insz <= 0) return 0;
   const Geo g = geometry(n, h, w, insz);
   // records + forward slabs (also reused as the per-pixel gradient buffers in backward)
-  const size_t rec = size_t(n) * NREC * g.N;
+  const size_t rec = rec_elems(n, g.N);
   const size_t slabs = size_t(g.nsplit) * n * 3 * HB * HB;
   const size_t bwd = size_t(n) * 3 * HB * HB + size_t(n) * 9 * g.N + size_t(n) * 3 * g.N;
   return (rec + std::max(slabs, bwd)) * sizeof(float);
@@ -480,13 +488,16 @@ extern "C" int st_rgbuv_hist_fwd(const float* x, float* hist, float* totals, flo
   const Geo g = geometry(n, h, w, insz);
   hipStream_t s = (hipStream_t)stream;
   float* rec = workspace;
-  float* slabs = workspace + size_t(n) * NREC * g.N;
+  float* slabs = workspace + rec_elems(n, g.N);
   const long long total = (long long)n * g.N;
   hipLaunchKernelGGL(hist_prep_kernel, dim3((int)std::min<long long>(st::cdivll(total, NT), 2048)), dim3(NT),
                      0, s, x, rec, c, h, w, g.hs, g.ws, g.resize, hp.intensity_scale, total);
   hipLaunchKernelGGL(hist_accum_kernel, dim3(g.nsplit, 3, n), dim3(NT), 0, s, rec, slabs, g.N, n,
                      g.chunks_per_split, hp);
-  hipLaunchKernelGGL(hist_finalize_kernel, dim3(n), dim3(NT), 0, s, slabs, g.nsplit, n, hist, totals);
+  // the pixel records are dead once the slabs exist: their head holds the per-block partial totals
+  static_assert(HIST_E % NT == 0, "one histogram element per thread");
+  hipLaunchKernelGGL(hist_sum_slabs_kernel, dim3(HIST_PARTS, n), dim3(NT), 0, s, slabs, g.nsplit, n, hist, rec);
+  hipLaunchKernelGGL(hist_normalize_kernel, dim3(HIST_PARTS, n), dim3(NT), 0, s, hist, rec, totals);
   return st::check_launch("st_rgbuv_hist_fwd");
 }
 
@@ -504,7 +515,7 @@ extern "C" int st_rgbuv_hist_bwd(const float* x, const float* hist, const float*
   const Geo g = geometry(n, h, w, insz);
   hipStream_t s = (hipStream_t)stream;
   float* rec = workspace;
-  float* draw = workspace + size_t(n) * NREC * g.N;
+  float* draw = workspace + rec_elems(n, g.N);
   float* gpix = draw + size_t(n) * 3 * HB * HB;
   float* gs = gpix + size_t(n) * 9 * g.N;
   const long long total = (long long)n * g.N;

@@ -21,14 +21,21 @@ class _KernelTimer:
     def __init__(self):
         self.enabled = False
         self._pending = []
+        self._pool = []
 
-    def start(self):
+    def start(self, prealloc: int = 0):
+        """``prealloc``: number of launches expected; their events are created here, outside any
+        timed region (creating HIP events inside it showed up as launch gaps on a fresh box)."""
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * prealloc)]
         self.enabled = True
         self._pending = []
 
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+
     def record(self, kernel: str, flops: float, nbytes: float):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        e0 = self._event()
+        e1 = self._event()
         self._pending.append((kernel, flops, nbytes, e0, e1))
         e0.record()
         return e1
