@@ -162,7 +162,7 @@ class Trainer:
     """Constructor keywords, optimizer names, checkpoint layout and resume rules of the reference
     Trainer (trainer.py:39-108, 201-232, 304-388, 607-655).  Extra keywords (all optional):
     ``encoder_weights`` / ``decoder_weights`` / ``vgg_weights`` (paths or state dicts; the blobs
-    the reference hard-codes are not shipped), ``device``."""
+    the reference hard-codes are not shipped), ``device``, ``compute_dtype`` ("f32" | "bf16")."""
 
     def __init__(self, dataloaders, output_dir: str, num_train_epochs: int, per_device_batch_size: int,
                  learning_rate: float, alpha: float, beta: float, gamma: float, seed: int = 42,
@@ -174,7 +174,8 @@ class Trainer:
                  step_frequency: float = 0.5, gradient_threshold: float = None, config: Namespace = None,
                  grayscale_content_transform: bool = False, use_VincentStyleLoss: bool = False,
                  content_layers_idx: List[int] = [12, 16, 21], style_layers_idx: List[int] = [0, 5, 10, 19, 28],
-                 encoder_weights=None, decoder_weights=None, vgg_weights=None, device=None):
+                 encoder_weights=None, decoder_weights=None, vgg_weights=None, device=None,
+                 compute_dtype: str = "f32"):
         self.output_dir = output_dir
         self.dataloaders = dataloaders.__call__() if callable(dataloaders) else dataloaders
         self.per_device_batch_size = per_device_batch_size
@@ -202,6 +203,7 @@ class Trainer:
         self.device = torch.device(device) if device is not None else \
             torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.encoder_weights, self.decoder_weights, self.vgg_weights = encoder_weights, decoder_weights, vgg_weights
+        self.compute_dtype = compute_dtype       # "f32" | "bf16" (precision.py)
         if self.with_tracking:
             raise RuntimeError("wandb tracking is outside the hot path this build covers (SURVEY.md section 2)")
         self.wandb = None
@@ -369,6 +371,8 @@ class Trainer:
         return losses
 
     def train(self):
+        from . import precision
+        precision.set_compute_dtype(self.compute_dtype)
         encoder, decoder, transformer, loss_vgg = self.build_model()
         params = self.trainable_parameters(transformer, decoder)
         transformer_optimizer = self.get_optimizer(self.optim_name['optim_name'], params, self.learning_rate,
@@ -411,11 +415,78 @@ class Trainer:
                       f"style {avg_style} variation {avg_var} hist {avg_hist} eps(style, content) {epss}")
             info = {"total": avg_total, "content": avg_content, "style": avg_style, "epoch": epoch,
                     "completed_step": completed_step}
+            plots = None
+            if self.do_eval_per_epoch and avg_total == min(loss_list) and self.save_best and self.rank == 0:
+                plots = self.evaluate_plots(encoder, decoder, transformer)       # trainer.py:530-559
             if (avg_total == min(loss_list) and self.save_best) or not self.save_best:   # trainer.py:580-595
-                self.save(transformer, transformer_optimizer, decoder, info=info, result=None)
+                self.save(transformer, transformer_optimizer, decoder, info=info, result=plots)
         return history
 
     # ---- inference composition --------------------------------------------------------------
+    @staticmethod
+    @torch.no_grad()
+    def plot_comparison(encoder, decoder, transformer, content_img_url: list, style_img_url: list, device='cpu',
+                        content_transformation=None, style_transformation=None, sleep: int = 5,
+                        plot: bool = True, alpha: float = 1.0):
+        """Trainer.plot_comparison (trainer.py:672-747): like the reference, only the LAST (content, style)
+        pair of the two lists is used; returns (pyplot module holding the 10x4 in figure, normalised decoded
+        image [1,3,H,W]).  The blend of :702 is fused into the AdaIN kernel."""
+        from PIL import Image
+        import numpy as np
+        from . import transforms as T
+        content_image = style_image = None
+        for content_url, style_url in zip(content_img_url, style_img_url):
+            content_image = Image.open(content_url).convert('RGB')
+            style_image = Image.open(style_url).convert('RGB')
+        content_image_tensor = content_transformation(content_image).to(device)
+        content_image_tensor_org = T.Compose([T.Resize(256), T.ToTensor()])(content_image)
+        style_image_tensor = style_transformation(style_image).to(device)
+        transformer.eval()
+        decoder.eval()
+        decode_img = Trainer.stylize(encoder, decoder, transformer, content_image_tensor.unsqueeze(0).contiguous(),
+                                     style_image_tensor.unsqueeze(0).contiguous(), alpha=alpha, normalize=True)
+        import matplotlib
+        if not plot:
+            matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        imgs = [content_image_tensor_org.squeeze().permute(1, 2, 0).detach().cpu().numpy(),
+                style_image_tensor.squeeze().permute(1, 2, 0).detach().cpu().numpy(),
+                decode_img.squeeze().permute(1, 2, 0).detach().cpu().numpy()]
+        fig, axes = plt.subplots(nrows=1, ncols=3, figsize=(10, 4))
+        for ax, im, title in zip(axes, imgs, ('Content', 'Style', 'Stylized content')):
+            ax.imshow(np.interp(im, (im.min(), im.max()), (0, 1)))
+            ax.set_title(title)
+            ax.axis('off')
+        plt.tight_layout()
+        if plot:
+            plt.show(block=False)
+            plt.pause(sleep)
+        return plt, decode_img
+
+    def evaluate_plots(self, encoder, decoder, transformer):
+        """The per-epoch eval grid of trainer.py:530-559: one 1000x400 RGBA comparison per eval batch."""
+        import io
+        from PIL import Image
+        from . import transforms as T
+        plots = []
+        for batch in self.dataloaders.get('eval', []):
+            plot, _ = self.plot_comparison(
+                encoder, decoder, transformer, batch['content_image'], batch['style_image'],
+                content_transformation=T.Compose([T.Resize(256), T.ToTensor(),
+                                                  T.RGBToGrayscaleStacked(enable=self.grayscale_content_transform)]),
+                style_transformation=T.Compose([T.Resize(256), T.ToTensor()]),
+                device=self.device, plot=self.plot_per_epoch)
+            try:
+                io_buf = io.BytesIO()
+                plot.savefig(io_buf, format='raw')
+                plot.close('all')
+                io_buf.seek(0)
+                plots.append(Image.frombytes('RGBA', (1000, 400), io_buf.getvalue(), 'raw'))
+                io_buf.close()
+            except Exception:
+                warnings.warn("Byte IO fail!")
+        return plots
+
     @staticmethod
     @torch.no_grad()
     def stylize(encoder, decoder, transformer, content: torch.Tensor, style: torch.Tensor, alpha: float = 1.0,

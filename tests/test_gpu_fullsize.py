@@ -1,0 +1,99 @@
+"""Parity at BASELINE's full sizes (configs[1] 512x512 batch 16, configs[4] 2048x2048), where the CPU oracle
+cannot run the whole tensor in seconds: crop-consistency against the oracle (a conv stack's interior does not
+depend on pixels outside its receptive field) and size-independent properties of AdaIN."""
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def models():
+    from style_transfer_amd.generator import Decoder, Encoder
+    enc_sd, dec_sd = R.make_encoder_state(0), R.make_decoder_state(1)
+    enc = Encoder(weights=enc_sd).cuda().eval()
+    dec = Decoder().cuda().eval()
+    dec.load_state_dict(dec_sd)
+    return enc, dec, enc_sd, dec_sd
+
+
+@pytest.mark.parametrize("side,batch", [(2048, 1), (512, 16)])
+def test_encoder_full_size_matches_oracle_on_crops(models, side, batch):
+    """relu4_1 features of the full image vs the oracle on 320x320 corner crops.  A feature at (i, j) depends on
+    input pixels within < 64 px of (8i, 8j) (three pools, nine 3x3 convs), so the 32x32 features nearest the image
+    corner of a crop are exact; the image-border side exercises the edge-replicate padding at full size."""
+    enc, _, enc_sd, _ = models
+    g = torch.Generator().manual_seed(side)
+    x = torch.rand(batch, 3, side, side, generator=g)
+    with torch.no_grad():
+        f = enc(x.cuda())
+    torch.cuda.synchronize()
+    assert f.shape == (batch, 512, side // 8, side // 8)
+    n = batch - 1
+    tl = R.encoder_forward(x[n:n + 1, :, :320, :320], enc_sd)
+    br = R.encoder_forward(x[n:n + 1, :, -320:, -320:], enc_sd)
+    assert rel_err(f[n:n + 1, :, :32, :32], tl[:, :, :32, :32]) < 1e-3
+    assert rel_err(f[n:n + 1, :, -32:, -32:], br[:, :, -32:, -32:]) < 1e-3
+
+
+def test_decoder_full_size_matches_oracle_on_crops(models):
+    """Decoder 256x256 features -> 2048x2048 image vs the oracle on a 48x48 feature corner (output pixels more than
+    ~6 feature cells away from the crop's cut edges are exact)."""
+    _, dec, _, dec_sd = models
+    g = torch.Generator().manual_seed(7)
+    t = torch.rand(1, 512, 256, 256, generator=g)
+    with torch.no_grad():
+        y = dec(t.cuda())
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 2048, 2048)
+    tl = R.decoder_forward(t[:, :, :48, :48], dec_sd)
+    br = R.decoder_forward(t[:, :, -48:, -48:], dec_sd)
+    assert rel_err(y[:, :, :320, :320], tl[:, :, :320, :320]) < 1e-3
+    assert rel_err(y[:, :, -320:, -320:], br[:, :, -320:, -320:]) < 1e-3
+
+
+@pytest.mark.parametrize("alpha", [0.5, 1.0, 1.5])
+def test_adain_config5_planes(alpha):
+    """AdaIN on 256x256 feature planes (a 2048x2048 image; 256 KB per plane: the streaming kernel) for the alpha
+    sweep of configs[4], against the oracle on the full tensor, plus the statistics property: at alpha = 1 every
+    output plane has the style plane's mean and (unbiased, eps-shifted) standard deviation."""
+    from style_transfer_amd import ops
+    g = torch.Generator().manual_seed(11)
+    c = torch.randn(1, 512, 256, 256, generator=g) * 2 + 1
+    s = torch.randn(1, 512, 256, 240, generator=g) * 0.5 - 3       # style plane of a different size
+    out, _ = ops.adain(c.cuda(), s.cuda(), 1e-5, 1e-5, alpha)
+    torch.cuda.synchronize()
+    ref = R.blend(R.adain_forward(c, s, torch.tensor([1e-5]), torch.tensor([1e-5]), 1e-5), c, alpha)
+    assert rel_err(out, ref) < 1e-4
+    if alpha == 1.0:
+        m, sd = ops.mean_std(out, 1e-5)
+        sm, ssd = R.calc_mean_std(s, 1e-5)
+        assert rel_err(m, sm) < 1e-4 and rel_err(sd, ssd) < 1e-3
+
+
+def test_stylize_2048_alpha_linearity(models):
+    """Whole pipeline at 2048x2048: decoding alpha-blended features is what stylize(alpha) does -- the blend is
+    fused into the AdaIN kernel, so stylize(alpha) must equal decoder(alpha*t + (1-alpha)*fc) built from the
+    alpha=1 features."""
+    from style_transfer_amd.pipeline import stylize
+    from style_transfer_amd.transformer import AdaIN
+    enc, dec, _, _ = models
+    ada = AdaIN().cuda()
+    g = torch.Generator().manual_seed(3)
+    c = torch.rand(1, 3, 2048, 2048, generator=g).cuda()
+    s = torch.rand(1, 3, 2048, 2048, generator=g).cuda()
+    with torch.no_grad():
+        fc, fs = enc(c), enc(s)
+        t = ada(fc, fs, alpha=1.0)
+        for alpha in (0.5, 1.5):
+            want = dec((alpha * t + (1 - alpha) * fc).contiguous())
+            got = stylize(enc, dec, ada, c, s, alpha=alpha)
+            assert got.shape == (1, 3, 2048, 2048)
+            assert rel_err(got, want) < 1e-4
