@@ -109,15 +109,150 @@ __global__ __launch_bounds__(NT) void adain_reg_kernel(const float* __restrict__
   }
 }
 
+// ---- large planes (16K < hw <= 64K floats: 1024^2 .. 2048^2 images) -----------------------
+// 512 threads hold the whole content plane in registers (32 float4 each = 256 KB per block), so
+// it is read from HBM once, its statistics are the exact two-pass form on registers and the
+// output is written once.  The style plane is only needed for its two statistics: it is streamed
+// ONCE, accumulating d = x - K and d*d in fp64 with K = mean of the plane's first 512 elements
+// (shifted one-pass moments: with fp64 accumulators the cancellation in s2 - s1^2/n is far below
+// fp32 resolution), instead of being read twice.  Algorithmic traffic: content + style + out.
+constexpr int NTB = 512;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(NTB) void adain_big_kernel(const float* __restrict__ content,
+                                                       const float* __restrict__ style,
+                                                       float* __restrict__ out, int hw_c, int hw_s,
+                                                       float eps_c, float eps_s, float alpha,
+                                                       float* __restrict__ stats) {
+  constexpr int V4 = 32, NW = NTB / 64;
+  __shared__ float red[NW];
+  __shared__ double redd[2 * NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t plane = blockIdx.x;
+  const float4* c4 = reinterpret_cast<const float4*>(content + plane * hw_c);
+  const float4* s4 = reinterpret_cast<const float4*>(style + plane * hw_s);
+  float4* o4 = reinterpret_cast<float4*>(out + plane * hw_c);
+  const int n4c = hw_c >> 2, n4s = hw_s >> 2;
+
+  float4 cv[V4];
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int idx = tid + i * NTB;
+    cv[i] = idx < n4c ? c4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // style shift K: mean of the first min(1024, hw_s) elements
+  const float* sp = style + plane * hw_s;
+  const int nk = min(NTB, hw_s);
+  float k0 = tid < nk ? sp[tid] : 0.f;
+  k0 = st::wave_sum(k0);
+  if (lane == 0) red[wave] = k0;
+  __syncthreads();
+  float K = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) K += red[w];
+  K /= float(nk);
+  // one pass over the style plane, 8 float4 in flight per thread
+  double s1 = 0.0, s2 = 0.0;
+  for (int base = tid; base < n4s; base += 8 * NTB) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NTB;
+      v[u] = idx < n4s ? s4[idx] : make_float4(K, K, K, K);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float a = v[u].x - K, b = v[u].y - K, c = v[u].z - K, d = v[u].w - K;
+      s1 += double((a + b) + (c + d));
+      s2 += double(a * a + b * b) + double(c * c + d * d);
+    }
+  }
+  // content sum (registers)
+  float sc = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) sc += (cv[i].x + cv[i].y) + (cv[i].z + cv[i].w);
+  sc = st::wave_sum(sc);
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  __syncthreads();
+  if (lane == 0) { red[wave] = sc; redd[wave] = s1; redd[NW + wave] = s2; }
+  __syncthreads();
+  float tc = 0.f;
+  double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { tc += red[w]; t1 += redd[w]; t2 += redd[NW + w]; }
+  const float mean_c = tc / float(hw_c);
+  const double ns = double(hw_s);
+  const float mean_s = float(double(K) + t1 / ns);
+  const float var_s = float((t2 - t1 * t1 / ns) / (ns - 1.0));
+  float qc = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int idx = tid + i * NTB;
+    if (idx < n4c) {
+      const float a = cv[i].x - mean_c, b = cv[i].y - mean_c, c = cv[i].z - mean_c, d = cv[i].w - mean_c;
+      qc += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  qc = st::wave_sum(qc);
+  __syncthreads();
+  if (lane == 0) red[wave] = qc;
+  __syncthreads();
+  tc = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) tc += red[w];
+  const float std_c = sqrtf(tc / float(hw_c - 1) + eps_c);
+  const float std_s = sqrtf(fmaxf(var_s, 0.f) + eps_s);
+  if (stats && tid == 0) reinterpret_cast<float4*>(stats)[plane] = make_float4(mean_c, std_c, mean_s, std_s);
+  const float inv_c = 1.f / std_c, beta = 1.f - alpha;
+  const float ga = alpha * inv_c * std_s + beta, gb = alpha * (mean_s - mean_c * inv_c * std_s);
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int idx = tid + i * NTB;
+    if (idx < n4c) {
+      // out = ga * x + gb  (in place: no second register set)
+      cv[i].x = fmaf(ga, cv[i].x, gb);
+      cv[i].y = fmaf(ga, cv[i].y, gb);
+      cv[i].z = fmaf(ga, cv[i].z, gb);
+      cv[i].w = fmaf(ga, cv[i].w, gb);
+      o4[idx] = cv[i];
+    }
+  }
+}
+
 // ---- streaming helpers (any hw, any alignment) ------------------------------------------
 __device__ __forceinline__ Stats plane_stats(const float* __restrict__ p, int hw, float* red) {
+  // 16-B loads when the plane allows it (every NCHW plane of the model does: hw % 4 == 0)
+  const bool vec = (hw & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+  const int n4 = hw >> 2;
   float s = 0.f;
-  for (int i = threadIdx.x; i < hw; i += NT) s += p[i];
+  if (vec) {
+    for (int i = threadIdx.x; i < n4; i += NT) {
+      const float4 v = p4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < hw; i += NT) s += p[i];
+  }
   const float mean = st::block_sum<NT>(s, red) / float(hw);
   float q = 0.f;
-  for (int i = threadIdx.x; i < hw; i += NT) {
-    const float d = p[i] - mean;
-    q += d * d;
+  if (vec) {
+    for (int i = threadIdx.x; i < n4; i += NT) {
+      const float4 v = p4[i];
+      const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  } else {
+    for (int i = threadIdx.x; i < hw; i += NT) {
+      const float d = p[i] - mean;
+      q += d * d;
+    }
   }
   Stats r;
   r.mean = mean;
@@ -264,6 +399,9 @@ extern "C" int st_adain_fwd(const float* content, const float* style, float* out
                        hw_style, eps_content, eps_style, alpha, stats);
   } else if (vec_ok && need <= NT * 4 * 16) {
     hipLaunchKernelGGL(adain_reg_kernel<16>, grid, block, 0, s, content, style, out, hw_content,
+                       hw_style, eps_content, eps_style, alpha, stats);
+  } else if (vec_ok && hw_content <= NTB * 4 * 32 && hw_style >= 2) {
+    hipLaunchKernelGGL(adain_big_kernel, grid, dim3(NTB), 0, s, content, style, out, hw_content,
                        hw_style, eps_content, eps_style, alpha, stats);
   } else {
     hipLaunchKernelGGL(adain_stream_kernel, grid, block, 0, s, content, style, out, hw_content,
