@@ -152,12 +152,31 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (the HIP hot path has no CPU fallback)")
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        # ST_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- a code-path rehearsal of N > 1 on a 1-GPU box
+        rehearsal = bool(os.environ.get("ST_BENCH_REHEARSAL"))
+        dev_index = 0 if rehearsal else self.local_rank
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=self.dev)
+            if rehearsal:
+                dist.init_process_group("gloo")
+                # gloo's CUDA path opens a stream per collective; with both ranks on one GPU and 4 hardware
+                # queues per process those streams can wait on each other forever.  The rehearsal checks the
+                # control flow (same collectives, same order, no rank-dependent branches), so stage through host.
+                _all_reduce = dist.all_reduce
+
+                def _host_all_reduce(t, op=dist.ReduceOp.SUM, **kw):
+                    if t.is_cuda:
+                        c = t.detach().cpu()
+                        _all_reduce(c, op=op)
+                        t.copy_(c)
+                    else:
+                        _all_reduce(t, op=op)
+                dist.all_reduce = _host_all_reduce
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)     # RCCL over xGMI
             self.dist = dist
 
     def barrier(self):
@@ -175,10 +194,17 @@ class Ctx:
 def timed(ctx: Ctx, fn, steps: int, warmup: int, collect_kernels: bool):
     from style_transfer_amd import ops
     # clock / allocator pre-warm (not a step: a fresh box runs its first ~1 s about 4 % slow), then W warmup steps
-    t_end = time.perf_counter() + PREWARM_SECONDS
-    while time.perf_counter() < t_end:
+    # (the iteration count is agreed over the ranks: a step may contain collectives)
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    n_pre = int(ctx.max_over_ranks(min(50.0, PREWARM_SECONDS / max(1e-4, time.perf_counter() - t0))))
+    for i in range(n_pre):
         fn()
-        torch.cuda.synchronize()
+        if os.environ.get("ST_BENCH_WATCHDOG"):
+            torch.cuda.synchronize()
+            print(f"[rank {ctx.rank}] pre-warm {i + 1}/{n_pre} {time.perf_counter() - t0:.2f}s", flush=True)
+    torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     ctx.barrier()
@@ -349,6 +375,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 compute-mode legs (BASELINE configs[3] shape)")
     args = ap.parse_args()
+    if os.environ.get("ST_BENCH_WATCHDOG"):      # dump every thread's stack and exit if the run hangs
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ST_BENCH_WATCHDOG"]), exit=True)
 
     ctx = Ctx()
     line = {}
