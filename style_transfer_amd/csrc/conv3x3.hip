@@ -44,7 +44,7 @@ struct ConvParams {
   int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
   int up, pad_zero, relu;
-  int tiles_x, tiles_y;
+  int tiles_x, tiles_y, ctiles, xcd_swizzle;
 };
 
 template <int MT, int NT, int WM, int WP>
@@ -73,12 +73,26 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WP, wp = wave % WP;
 
-  int bt = blockIdx.x;
+  // Block -> (pixel tile, channel tile).  Blocks are dealt round-robin over the 8 XCDs (each with
+  // its own L2), so ids that differ by 8 share an XCD: the channel tiles of one pixel tile get
+  // consecutive slots on ONE XCD and the 2..4 reads of the same activation tile hit its L2.
+  int bt, ct;
+  {
+    const int id = blockIdx.x;
+    if (p.xcd_swizzle) {
+      const int k = id >> 3;
+      ct = k % p.ctiles;
+      bt = (k / p.ctiles) * 8 + (id & 7);
+    } else {
+      ct = id % p.ctiles;
+      bt = id / p.ctiles;
+    }
+  }
   const int tx = bt % p.tiles_x;
   bt /= p.tiles_x;
   const int ty = bt % p.tiles_y;
   const int b = bt / p.tiles_y;
-  const int m0 = blockIdx.y * C::BM;
+  const int m0 = ct * C::BM;
   const int x0 = tx * TW, y0 = ty * C::TH;
 
   // ---- per-thread source offsets of the halo positions this thread stages -------------
@@ -272,8 +286,10 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   p.tiles_x = st::cdiv(p.Wo, TW);
   p.tiles_y = st::cdiv(p.Ho, C::TH);
   const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
-  ST_REQUIRE(ptiles <= 0x7fffffffLL, "st_conv3x3: too many pixel tiles (%lld)", ptiles);
-  dim3 grid((unsigned)ptiles, (unsigned)st::cdiv(p.cout, C::BM));
+  p.ctiles = st::cdiv(p.cout, C::BM);
+  ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3: too many tiles (%lld)", ptiles * p.ctiles);
+  p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
+  dim3 grid((unsigned)(ptiles * p.ctiles));
   hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP, GATE>), grid, dim3(NTHREADS),
                      C::LDS_BYTES, stream, p);
   return st::check_launch("st_conv3x3");
