@@ -313,7 +313,8 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
     from style_transfer_amd.trainer import GradBucket, Trainer
 
     dev = ctx.dev
-    with warnings.catch_warnings():
+    import contextlib
+    with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):   # stdout carries ONLY the JSON line
         warnings.simplefilter("ignore")
         tr = Trainer({"train": []}, output_dir="/tmp/st_bench", num_train_epochs=1,
                      per_device_batch_size=args.train_batch, learning_rate=1e-4, alpha=1.0, beta=10.0, gamma=1.0,

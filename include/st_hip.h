@@ -114,6 +114,12 @@ int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_pa
                           float* workspace, int n, int cout, int h, int w, int cin, int upsample2x,
                           int pad_mode, st_stream_t stream);
 
+/* bf16-operand weight / bias gradient; same arguments, outputs (fp32 dw / dbias) and workspace
+ * (st_conv3x3_wgrad_workspace_bytes) as st_conv3x3_wgrad. */
+int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const float* y_gate, float* dw,
+                          float* dbias, float* workspace, int n, int cin, int hin, int win, int cout,
+                          int upsample2x, int pad_mode, st_stream_t stream);
+
 /* ---- SymmetricPadding2D.forward, any padding (generator.py:14-39) ----------------------
  * numpy-"symmetric" reflection about the half-pixel points -0.5 and n-0.5 (edge pixel
  * repeated).  x: [nc][h][w] -> y: [nc][h+top+bottom][w+left+right].  The fused 3x3 conv

@@ -80,7 +80,7 @@ class conv_compute:
     """Context manager: ``with conv_compute("bf16"):`` makes every 3x3 convolution of this module
     round its operands (activations, weights, and the output gradient in the data-gradient) to
     bf16 with fp32 accumulation -- the numerics of style_transfer_amd's bf16 compute mode
-    (csrc/conv3x3_bf16.hip); the weight gradient stays fp32 like the HIP path."""
+    (csrc/conv3x3_bf16.hip, conv3x3_wgrad.hip); the bias gradient sums the unrounded gradient."""
 
     def __init__(self, name: str):
         assert name in ("f32", "bf16")
@@ -109,7 +109,7 @@ class _ConvBf16Operands(torch.autograd.Function):
     def backward(ctx, gy):
         xp, w = ctx.saved_tensors
         gx = torch.nn.grad.conv2d_input(xp.shape, _round_bf16(w), _round_bf16(gy)) if ctx.needs_input_grad[0] else None
-        gw = torch.nn.grad.conv2d_weight(xp, w.shape, gy) if ctx.needs_input_grad[1] else None
+        gw = torch.nn.grad.conv2d_weight(_round_bf16(xp), w.shape, _round_bf16(gy)) if ctx.needs_input_grad[1] else None
         gb = gy.sum((0, 2, 3)) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 

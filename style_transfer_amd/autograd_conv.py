@@ -35,7 +35,7 @@ class Conv3x3Function(torch.autograd.Function):
             dx = ops.conv3x3_dgrad(dy, y, wpt, int(weight.shape[1]), ctx.upsample2x, ctx.pad_mode)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = ops.conv3x3_wgrad(x, dy, y, want_bias=ctx.has_bias, upsample2x=ctx.upsample2x,
-                                       pad_mode=ctx.pad_mode)
+                                       pad_mode=ctx.pad_mode, compute=ctx.compute)
             if not ctx.needs_input_grad[1]:
                 dw = None
             if not (ctx.has_bias and ctx.needs_input_grad[2]):

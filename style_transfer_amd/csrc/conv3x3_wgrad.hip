@@ -234,14 +234,223 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// ================================================================================================
+// bf16 compute mode (BASELINE configs[3]): the same GEMM with bf16 operands and fp32 accumulation,
+// v_mfma_f32_32x32x16_bf16, K step = 16 consecutive pixels of one tile row.
+//   * A lane supplies 8 consecutive K values, so both LDS images are pixel-innermost bf16:
+//       G  [128 o][4 rows x 32 px]                  row stride 272 B
+//       Xk [3 kx][32 c][6 halo rows][32 px]         one copy per horizontal tap shift, so that the 8
+//                                                   pixels of every (c, ky, kx) column start 16-B aligned
+//     strides (rows 80 B, channels 496 B, copies 15984 B) found by exhaustive search: the 16 lanes of
+//     every ds_read_b128 group hit 16 distinct 4-bank sets for all nine column tiles.
+//   * 12 waves as in the fp32 kernel (wave = 1 channel tile x 3 column tiles), 128-pixel tiles
+//     (8 K steps), next tile's global loads in flight during the MFMA phase.
+//   * fp32 slabs / fixed-order reduction / bias gradient exactly as above.
+namespace bf {
+
+constexpr int TRB = 4;                      // pixel-tile rows
+constexpr int TPB = TRB * TW;               // 128 pixels = 8 K steps
+constexpr int HRB = TRB + 2;                // halo rows
+constexpr int G_ROW_B = TPB * 2 + 16;       // 272 bytes per channel row of G
+constexpr int X_ROW_B = 80, X_CH_B = 496, X_COPY_B = 15984;
+constexpr int G_BYTES = BO * G_ROW_B;       // 34816
+constexpr size_t LDS_BYTES_B = size_t(G_BYTES) + 3 * X_COPY_B;   // 82768
+constexpr int NG4B = BO * TRB * (TW / 4);   // float4 of one dy tile = 4096
+constexpr int NGPB = (NG4B + NTHREADS - 1) / NTHREADS;           // 6
+static_assert(CI * HRB * 4 == NTHREADS, "one halo staging item per thread");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool GATE>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
+  unsigned char* Gs = smemb;
+  unsigned char* Xs = smemb + G_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int c0 = blockIdx.x * CI;
+  const int o0 = blockIdx.y * BO;
+  const int split = blockIdx.z;
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
+
+  // halo staging item of this thread: channel xc, halo row xr, 8-pixel group xq
+  const int xq = tid & 3, xr = (tid >> 2) % HRB, xc = tid / (4 * HRB);
+  const bool vec4 = (p.W & 3) == 0;
+  const size_t plane_src = size_t(p.hs) * p.ws;
+  const size_t plane_out = size_t(p.H) * p.W;
+
+  f32x16 acc[WJT];
+#pragma unroll
+  for (int t = 0; t < WJT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bias_acc[NGPB];
+#pragma unroll
+  for (int i = 0; i < NGPB; ++i) bias_acc[i] = 0.f;
+
+  const int ot = wave & 3, jt0 = (wave >> 2) * WJT;
+  const unsigned char* aPtr = Gs + (ot * 32 + li) * G_ROW_B + lh * 16;
+  int bOff[WJT];
+#pragma unroll
+  for (int jt = 0; jt < WJT; ++jt) {
+    const int j = (jt0 + jt) * 32 + li;
+    const int c = j / 9, tap = j - c * 9;
+    bOff[jt] = (tap % 3) * X_COPY_B + c * X_CH_B + (tap / 3) * X_ROW_B + lh * 16;
+  }
+
+  f32x4 gv[NGPB];
+  float xv[10];
+
+#define ST_WG_LOAD(t_)                                                                          \
+  {                                                                                             \
+    int rem = (t_);                                                                             \
+    const int tx = rem % p.tiles_x;                                                             \
+    rem /= p.tiles_x;                                                                           \
+    const int ty = rem % p.tiles_y;                                                             \
+    const int b = rem / p.tiles_y;                                                              \
+    const int x0 = tx * TW, y0 = ty * TRB;                                                      \
+    _Pragma("unroll") for (int i = 0; i < NGPB; ++i) {                                          \
+      const int g = min(tid + i * NTHREADS, NG4B - 1);                                          \
+      const int seg = g >> 3, q4 = g & 7;                                                       \
+      const int o = min(o0 + (seg >> 2), p.cout - 1);                                           \
+      const int cy = min(y0 + (seg & 3), p.H - 1);                                              \
+      const size_t base = (size_t(b) * p.cout + o) * plane_out + size_t(cy) * p.W;              \
+      if (vec4) {                                                                               \
+        const int cx = min(x0 + q4 * 4, p.W - 4);                                               \
+        gv[i] = *reinterpret_cast<const f32x4*>(p.dy + base + cx);                              \
+        if (GATE) {                                                                             \
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(p.ygate + base + cx);                \
+          _Pragma("unroll") for (int k = 0; k < 4; ++k) gv[i][k] = yv[k] > 0.f ? gv[i][k] : 0.f; \
+        }                                                                                       \
+      } else {                                                                                  \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                         \
+          const int cx = min(x0 + q4 * 4 + k, p.W - 1);                                         \
+          gv[i][k] = p.dy[base + cx];                                                           \
+          if (GATE) gv[i][k] = p.ygate[base + cx] > 0.f ? gv[i][k] : 0.f;                       \
+        }                                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+    {                                                                                           \
+      const int gy = y0 + xr - 1;                                                               \
+      int cy = min(max(gy, 0), p.H - 1);                                                        \
+      if (p.up) cy >>= 1;                                                                       \
+      const float* xrow = p.x + (size_t(b) * p.cin + min(c0 + xc, p.cin - 1)) * plane_src +     \
+                          size_t(cy) * p.ws;                                                    \
+      _Pragma("unroll") for (int k = 0; k < 10; ++k) {                                          \
+        int cx = min(max(x0 + xq * 8 + k - 1, 0), p.W - 1);                                     \
+        if (p.up) cx >>= 1;                                                                     \
+        xv[k] = xrow[cx];                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+#define ST_WG_STORE(t_)                                                                         \
+  {                                                                                             \
+    int rem = (t_);                                                                             \
+    const int tx = rem % p.tiles_x;                                                             \
+    rem /= p.tiles_x;                                                                           \
+    const int ty = rem % p.tiles_y;                                                             \
+    const int x0 = tx * TW, y0 = ty * TRB;                                                      \
+    _Pragma("unroll") for (int i = 0; i < NGPB; ++i) {                                          \
+      const int g = tid + i * NTHREADS;                                                         \
+      if (NG4B % NTHREADS != 0 && g >= NG4B) break;                                             \
+      const int seg = g >> 3, q4 = g & 7;                                                       \
+      const bool row_ok = (o0 + (seg >> 2)) < p.cout && (y0 + (seg & 3)) < p.H;                 \
+      bf16x4 pk;                                                                                \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                           \
+        const float gg = (row_ok && (x0 + q4 * 4 + k) < p.W) ? gv[i][k] : 0.f;                  \
+        pk[k] = (__bf16)gg;                                                                     \
+        bias_acc[i] += gg;                                                                      \
+      }                                                                                         \
+      *reinterpret_cast<u32x2*>(Gs + (seg >> 2) * G_ROW_B + ((seg & 3) * TW + q4 * 4) * 2) =    \
+          __builtin_bit_cast(u32x2, pk);                                                        \
+    }                                                                                           \
+    {                                                                                           \
+      const int gy = y0 + xr - 1;                                                               \
+      const bool rowin = gy >= 0 && gy < p.H;                                                   \
+      const bool chan_ok = (c0 + xc) < p.cin;                                                   \
+      float xm[10];                                                                             \
+      _Pragma("unroll") for (int k = 0; k < 10; ++k) {                                          \
+        const int gx = x0 + xq * 8 + k - 1;                                                     \
+        const bool inb = rowin && gx >= 0 && gx < p.W;                                          \
+        const unsigned m = ((inb || !p.pad_zero) && chan_ok) ? 0xffffffffu : 0u;                \
+        xm[k] = __uint_as_float(__float_as_uint(xv[k]) & m);                                    \
+      }                                                                                         \
+      _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                        \
+        bf16x8 pk;                                                                              \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) pk[k] = (__bf16)xm[k + kx];               \
+        *reinterpret_cast<u32x4*>(Xs + kx * X_COPY_B + xc * X_CH_B + xr * X_ROW_B + xq * 16) =  \
+            __builtin_bit_cast(u32x4, pk);                                                      \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+  if (t_begin < t_end) ST_WG_LOAD(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();   // previous tile's MFMA phase is done with LDS
+    ST_WG_STORE(t);
+    __syncthreads();
+    if (t + 1 < t_end) ST_WG_LOAD(t + 1);   // in flight during the MFMA phase
+#pragma unroll
+    for (int s = 0; s < TPB / 16; ++s) {
+      // K step s = pixels s*16 .. s*16+15 of the tile: row s/2, columns (s%2)*16 ..
+      const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(aPtr + s * 32));
+      const int poff = (s >> 1) * X_ROW_B + (s & 1) * 32;
+#pragma unroll
+      for (int jt = 0; jt < WJT; ++jt) {
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Xs + bOff[jt] + poff));
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[jt], 0, 0, 0);
+      }
+    }
+  }
+#undef ST_WG_LOAD
+#undef ST_WG_STORE
+
+  // ---- epilogue: partial slab, register row r = one output channel, 32 contiguous columns --
+  float* slab = p.slabs + size_t(split) * p.cout * p.cin * 9;
+#pragma unroll
+  for (int jt = 0; jt < WJT; ++jt) {
+    const int jg = c0 * 9 + (jt0 + jt) * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (o < p.cout && jg < p.cin * 9)
+        slab[size_t(o) * p.cin * 9 + jg] = acc[jt][r];
+    }
+  }
+  if (p.bias_slabs && blockIdx.x == 0) {
+    // a channel's 4 rows x 8 float4 sit in 32 consecutive lanes (g / 32 = channel)
+#pragma unroll
+    for (int i = 0; i < NGPB; ++i) {
+      float v = bias_acc[i];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      const int g = tid + i * NTHREADS;
+      const int o = o0 + (g >> 5);
+      if ((tid & 31) == 0 && g < NG4B && o < p.cout) p.bias_slabs[size_t(split) * p.cout + o] = v;
+    }
+  }
+}
+
+}  // namespace bf
+
 struct Plan {
   int tiles_x, tiles_y, ntiles, nsplit, tiles_per_split;
 };
 
-Plan make_plan(int n, int cout, int cin, int H, int W) {
+Plan make_plan(int n, int cout, int cin, int H, int W, int tile_rows = TR) {
   Plan pl;
   pl.tiles_x = st::cdiv(W, TW);
-  pl.tiles_y = st::cdiv(H, TR);
+  pl.tiles_y = st::cdiv(H, tile_rows);
   const long long nt = (long long)n * pl.tiles_x * pl.tiles_y;
   pl.ntiles = (int)std::min<long long>(nt, 0x7fffffff);
   const int ctiles = st::cdiv(cin, CI) * st::cdiv(cout, BO);
@@ -260,8 +469,9 @@ Plan make_plan(int n, int cout, int cin, int H, int W) {
 
 extern "C" size_t st_conv3x3_wgrad_workspace_bytes(int n, int cout, int cin, int h, int w) {
   if (n <= 0 || cout <= 0 || cin <= 0 || h <= 0 || w <= 0) return 0;
-  const Plan pl = make_plan(n, cout, cin, h, w);
-  return size_t(pl.nsplit) * (size_t(cout) * cin * 9 + cout) * sizeof(float);
+  // covers both the fp32 (2-row tiles) and the bf16 (4-row tiles) split plans
+  const int nsplit = std::max(make_plan(n, cout, cin, h, w).nsplit, make_plan(n, cout, cin, h, w, bf::TRB).nsplit);
+  return size_t(nsplit) * (size_t(cout) * cin * 9 + cout) * sizeof(float);
 }
 
 extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_gate, float* dw,
@@ -303,4 +513,53 @@ extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(st::cdiv(cout, 256)), dim3(256), 0, s,
                        p.bias_slabs, dbias, (long long)cout, pl.nsplit);
   return st::check_launch("st_conv3x3_wgrad(reduce)");
+}
+
+extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const float* y_gate, float* dw,
+                                     float* dbias, float* workspace, int n, int cin, int hin, int win,
+                                     int cout, int upsample2x, int pad_mode, st_stream_t stream) {
+  ST_REQUIRE(x && dy && dw && workspace, "st_conv3x3_wgrad_bf16: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
+             "st_conv3x3_wgrad_bf16: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO,
+             "st_conv3x3_wgrad_bf16: bad pad_mode %d", pad_mode);
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(dy) % 16 == 0 &&
+             (!y_gate || reinterpret_cast<uintptr_t>(y_gate) % 16 == 0),
+             "st_conv3x3_wgrad_bf16: dy / y_gate must be 16-byte aligned");
+  const int up = upsample2x ? 1 : 0;
+  const int H = hin << up, W = win << up;
+  ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, bf::TRB) <= 0x7fffffffLL,
+             "st_conv3x3_wgrad_bf16: too many pixel tiles");
+  const Plan pl = make_plan(n, cout, cin, H, W, bf::TRB);
+  WgradParams p;
+  p.dy = dy; p.ygate = y_gate; p.x = x;
+  p.slabs = workspace;
+  p.bias_slabs = dbias ? workspace + size_t(pl.nsplit) * cout * cin * 9 : nullptr;
+  p.n = n; p.cout = cout; p.cin = cin; p.hs = hin; p.ws = win; p.H = H; p.W = W;
+  p.up = up; p.pad_zero = pad_mode == ST_PAD_ZERO;
+  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
+  p.tiles_per_split = pl.tiles_per_split; p.nsplit = pl.nsplit;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {   // 82.8 KB of dynamic LDS (> the 64 KB default limit)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bf::conv3x3_wgrad_bf16_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf::LDS_BYTES_B);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bf::conv3x3_wgrad_bf16_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf::LDS_BYTES_B);
+    attr_set = true;
+  }
+  dim3 grid(st::cdiv(cin, CI), st::cdiv(cout, BO), pl.nsplit);
+  if (y_gate)
+    hipLaunchKernelGGL(bf::conv3x3_wgrad_bf16_kernel<true>, grid, dim3(NTHREADS), bf::LDS_BYTES_B, s, p);
+  else
+    hipLaunchKernelGGL(bf::conv3x3_wgrad_bf16_kernel<false>, grid, dim3(NTHREADS), bf::LDS_BYTES_B, s, p);
+  int rc = st::check_launch("st_conv3x3_wgrad_bf16");
+  if (rc != ST_OK) return rc;
+  const long long nw = (long long)cout * cin * 9;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(nw, 256), 2048)),
+                     dim3(256), 0, s, p.slabs, dw, nw, pl.nsplit);
+  if (dbias)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(st::cdiv(cout, 256)), dim3(256), 0, s,
+                       p.bias_slabs, dbias, (long long)cout, pl.nsplit);
+  return st::check_launch("st_conv3x3_wgrad_bf16(reduce)");
 }

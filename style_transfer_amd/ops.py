@@ -145,8 +145,10 @@ def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: 
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tensor], want_bias: bool = True,
-                  upsample2x: bool = False, pad_mode="replicate") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """(dW [cout,cin,3,3], dbias [cout] or None) of the fused conv layer."""
+                  upsample2x: bool = False, pad_mode="replicate",
+                  compute: str = "f32") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """(dW [cout,cin,3,3], dbias [cout] or None) of the fused conv layer; ``compute="bf16"`` rounds both
+    GEMM operands (gated dy and the padded input) to bf16, accumulation and outputs stay fp32."""
     lib = _lib.load()
     n, cin, h, w = (int(v) for v in x.shape)
     cout = int(dy.shape[1])
@@ -158,9 +160,10 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tens
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     ev = None
     if KERNEL_TIMER.enabled:
-        ev = KERNEL_TIMER.record("conv3x3_wgrad_kernel", 2.0 * n * h * s * w * s * cin * cout * 9,
-                                 4.0 * (dy.numel() + x.numel()))
-    _lib.check(lib.st_conv3x3_wgrad(_lib.dev_ptr(x, "x"), _lib.dev_ptr(dy, "dy"),
+        ev = KERNEL_TIMER.record("conv3x3_wgrad_bf16_kernel" if compute == "bf16" else "conv3x3_wgrad_kernel",
+                                 2.0 * n * h * s * w * s * cin * cout * 9, 4.0 * (dy.numel() + x.numel()))
+    fn = lib.st_conv3x3_wgrad_bf16 if compute == "bf16" else lib.st_conv3x3_wgrad
+    _lib.check(fn(_lib.dev_ptr(x, "x"), _lib.dev_ptr(dy, "dy"),
                                     _lib.dev_ptr(y_gate, "y_gate") if y_gate is not None else None,
                                     _lib.dev_ptr(dw, "dw"), _lib.dev_ptr(db, "db") if db is not None else None,
                                     _lib.dev_ptr(ws, "workspace"), n, cin, h, w, cout, int(upsample2x),

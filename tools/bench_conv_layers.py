@@ -49,7 +49,7 @@ def main():
         elif args.mode == "dgrad":
             fn = lambda: ops.conv3x3_dgrad(dy, y, wpt, cin, up, "replicate")
         else:
-            fn = lambda: ops.conv3x3_wgrad(x, dy, y, True, up, "replicate")
+            fn = lambda: ops.conv3x3_wgrad(x, dy, y, True, up, "replicate", compute=args.compute)
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
