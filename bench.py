@@ -374,6 +374,8 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--no-gram", action="store_true", help="skip the VincentStyleLoss variant of the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
+                    help="conv compute precision of the main legs (profiling aid; the headline legs are f32)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 compute-mode legs (BASELINE configs[3] shape)")
     args = ap.parse_args()
     if os.environ.get("ST_BENCH_WATCHDOG"):      # dump every thread's stack and exit if the run hangs
@@ -383,11 +385,11 @@ def main():
     ctx = Ctx()
     line = {}
     if args.mode in ("both", "infer"):
-        line = run_inference(ctx, args)
+        line = run_inference(ctx, args, compute=args.compute)
     if args.mode in ("both", "train"):
-        train = run_train(ctx, args, use_vincent=False)
+        train = run_train(ctx, args, use_vincent=False, compute=args.compute)
         if not args.no_gram:
-            train["gram"] = run_train(ctx, args, use_vincent=True)
+            train["gram"] = run_train(ctx, args, use_vincent=True, compute=args.compute)
         if args.mode == "train":
             line = dict(train, higher_is_better=True, vs_baseline=None, data="synthetic")
             train = None

@@ -26,6 +26,9 @@ inline int check_launch(const char* what) {
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// row stride (floats) of the padded (w + 2)-wide data-gradient workspace: a multiple of 4 so that rows
+// start 16-B aligned and the kernels can store 16 B per lane
+__host__ __device__ inline int padded_row(int w) { return (w + 2 + 3) & ~3; }
 inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
 
 }  // namespace st

@@ -41,6 +41,7 @@ struct ConvParams {
   int n, cin, hs, ws;      // source tensor dims
   int cout, H, W;          // conv-input spatial dims, after the optional upsample
   int Ho, Wo;              // output dims: (H, W) forward; (H+2, W+2) for the padded data gradient
+  int ldo;                 // output row stride in floats (Wo, or Wo rounded up to 4 in the padded workspace)
   int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
   int up, pad_zero, relu;
@@ -213,14 +214,14 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
         const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (co < p.cout) {
           const float bv = p.bias ? p.bias[co] : 0.f;
-          float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.Wo + xx;
+          float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.ldo + xx;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int yy = y0 + wp * NT + nt;
             if (yy < p.Ho) {
               float v = acc[mt][nt][r] + bv;
               if (p.relu) v = fmaxf(v, 0.f);
-              yrow[size_t(yy) * p.Wo] = v;
+              yrow[size_t(yy) * p.ldo] = v;
             }
           }
         }
@@ -258,7 +259,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 __global__ __launch_bounds__(256) void dgrad_fold_kernel(const float* __restrict__ dxp,
                                                         float* __restrict__ dx, int H, int W,
                                                         int up, int hs, int ws, long long total) {
-  const int Wp = W + 2;
+  const int Wp = st::padded_row(W);   // row stride of the padded workspace
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const int j = int(e % ws);
@@ -353,7 +354,7 @@ extern "C" int st_conv3x3_fwd(const float* x, const float* w_packed, const float
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
   p.up = upsample2x ? 1 : 0;
   p.H = hin << p.up; p.W = win << p.up;
-  p.Ho = p.H; p.Wo = p.W; p.shift = 0;
+  p.Ho = p.H; p.Wo = p.W; p.ldo = p.W; p.shift = 0;
   p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
   p.nchunks = st::cdiv(cin, KC);
   p.pad_zero = pad_mode == ST_PAD_ZERO;
@@ -363,7 +364,7 @@ extern "C" int st_conv3x3_fwd(const float* x, const float* w_packed, const float
 
 extern "C" size_t st_conv3x3_dgrad_workspace_bytes(int n, int cin, int h, int w, int pad_mode) {
   if (pad_mode != ST_PAD_REPLICATE) return 0;
-  return size_t(n) * cin * (h + 2) * (w + 2) * sizeof(float);
+  return size_t(n) * cin * (h + 2) * st::padded_row(w) * sizeof(float);
 }
 
 extern "C" int st_conv3x3_dgrad(const float* dy, const float* y_gate, const float* w_packed_t,
@@ -392,6 +393,7 @@ extern "C" int st_conv3x3_dgrad(const float* dy, const float* y_gate, const floa
   p.n = n; p.cin = cout; p.hs = h; p.ws = w; p.cout = cin;
   p.up = 0; p.H = h; p.W = w;
   p.Ho = rep ? h + 2 : h; p.Wo = rep ? w + 2 : w; p.shift = rep ? 1 : 0;
+  p.ldo = rep ? st::padded_row(w) : w;
   p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
   p.nchunks = st::cdiv(cout, KC);
   p.pad_zero = 1; p.relu = 0;

@@ -52,11 +52,12 @@ struct ConvParams {
   int n, cin, hs, ws;      // source tensor dims
   int cout, H, W;          // conv-input spatial dims, after the optional upsample
   int Ho, Wo;              // output dims: (H, W) forward; (H+2, W+2) for the padded data gradient
+  int ldo;                 // output row stride in floats (Wo, or Wo rounded up to 4 in the padded workspace)
   int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
   int up, pad_zero, relu;
   int tiles_x, tiles_y, ctiles, xcd_swizzle;
-  int vec_store;           // Wo % 4 == 0 and y 16-B aligned: 16-B-per-lane epilogue stores
+  int vec_store;           // ldo % 4 == 0 and y 16-B aligned: 16-B-per-lane epilogue stores
   int ablate;              // debug only (ST_BF16_ABLATE): 1 skip MFMA, 2 skip X staging, 4 skip W DMA
 };
 
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
           const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ch * 32 + x4);
           const int co = cbase + ch, xs = x0 + x4;
           if (co < p.cout && yy < p.Ho && xs < p.Wo)
-            *reinterpret_cast<f32x4*>(p.y + ((size_t(b) * p.cout + co) * p.Ho + yy) * p.Wo + xs) = v;
+            *reinterpret_cast<f32x4*>(p.y + ((size_t(b) * p.cout + co) * p.Ho + yy) * p.ldo + xs) = v;
         }
       }
     }
@@ -324,14 +325,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
           const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (co < p.cout) {
             const float bv = p.bias ? p.bias[co] : 0.f;
-            float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.Wo + xx;
+            float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.ldo + xx;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               const int yy = y0 + wp * NT + nt;
               if (yy < p.Ho) {
                 float v = acc[mt][nt][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
-                yrow[size_t(yy) * p.Wo] = v;
+                yrow[size_t(yy) * p.ldo] = v;
               }
             }
           }
@@ -379,7 +380,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   p.ctiles = st::cdiv(p.cout, C::BM);
   ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3_bf16: too many tiles (%lld)", ptiles * p.ctiles);
   p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
-  p.vec_store = (p.Wo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
+  p.vec_store = (p.ldo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
   dim3 grid((unsigned)(ptiles * p.ctiles));
   if (p.cin % KC == 0)
     hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false>), grid, dim3(NTHREADS),
@@ -448,7 +449,7 @@ extern "C" int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const f
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
   p.up = upsample2x ? 1 : 0;
   p.H = hin << p.up; p.W = win << p.up;
-  p.Ho = p.H; p.Wo = p.W; p.shift = 0;
+  p.Ho = p.H; p.Wo = p.W; p.ldo = p.W; p.shift = 0;
   p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
   p.nchunks = st::cdiv(cin, KC);
   p.pad_zero = pad_mode == ST_PAD_ZERO;
@@ -479,6 +480,7 @@ extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const
   p.n = n; p.cin = cout; p.hs = h; p.ws = w; p.cout = cin;
   p.up = 0; p.H = h; p.W = w;
   p.Ho = rep ? h + 2 : h; p.Wo = rep ? w + 2 : w; p.shift = rep ? 1 : 0;
+  p.ldo = rep ? st::padded_row(w) : w;
   p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
   p.nchunks = st::cdiv(cout, KC);
   p.pad_zero = 1; p.relu = 0;
