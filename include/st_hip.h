@@ -74,6 +74,13 @@ int st_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, flo
                    int n, int cin, int hin, int win, int cout,
                    int upsample2x, int pad_mode, int relu, st_stream_t stream);
 
+/* The same layer followed by MaxPool2d((2,2),(2,2),(0,0),ceil_mode=True) (generator.py:51-53, 58-60,
+ * 71-73) in ONE launch: ypool[n][cout][ceil(hin/2)][ceil(win/2)]; the full-resolution activation is
+ * never written.  Forward only (the encoder is frozen, trainer.py:286-297). */
+int st_conv3x3_pool_fwd(const float* x, const float* w_packed, const float* bias, float* ypool,
+                        int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
+                        st_stream_t stream);
+
 /* Data gradient of the layer above (decoder backward, trainer.py:472; loss-VGG backward).
  *   dy:      [n][cout][h][w]   gradient w.r.t. the layer output (h, w = OUTPUT dims)
  *   y_gate:  nullable; the layer's post-ReLU output: dy is taken as 0 where y_gate <= 0
@@ -109,6 +116,9 @@ int st_conv3x3_pack_weights_bf16(const float* w_oihw, void* w_packed, int cout, 
 int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* y,
                         int n, int cin, int hin, int win, int cout,
                         int upsample2x, int pad_mode, int relu, st_stream_t stream);
+int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* ypool,
+                             int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
+                             st_stream_t stream);
 /* workspace: st_conv3x3_dgrad_workspace_bytes() (same as the fp32 entry point) */
 int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t, float* dx,
                           float* workspace, int n, int cout, int h, int w, int cin, int upsample2x,

@@ -52,6 +52,7 @@ struct ConvParams {
   int n, cin, hs, ws;      // source tensor dims
   int cout, H, W;          // conv-input spatial dims, after the optional upsample
   int Ho, Wo;              // output dims: (H, W) forward; (H+2, W+2) for the padded data gradient
+  int pool;                // 1: the epilogue writes maxpool2x2(ceil_mode) of the activation instead of it
   int ldo;                 // output row stride in floats (Wo, or Wo rounded up to 4 in the padded workspace)
   int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
@@ -284,7 +285,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // becomes store-ISSUE-bound.  Each wave therefore transposes a tile through a private 4 KB LDS
   // patch (the staging buffers are free after the last barrier) and writes 16 B per lane: 8 lanes
   // cover one 128-B row segment, a wave instruction writes 8 channel rows.
-  if (p.vec_store) {
+  if (p.pool) {
+    // fused MaxPool2d((2,2),(2,2),ceil_mode=True) (generator.py:53,60,73), as in csrc/conv3x3.hip
+    static_assert(NT % 2 == 0, "row pairs live in one wave");
+    const int Hp = (p.Ho + 1) >> 1, Wp = (p.Wo + 1) >> 1;
+    const int xx = x0 + li;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bv = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt += 2) {
+          const int yy = y0 + wp * NT + nt;
+          float v = acc[mt][nt][r];
+          if (yy + 1 < p.Ho) v = fmaxf(v, acc[mt][nt + 1][r]);
+          const float vn = __shfl_xor(v, 1, 64);
+          if (xx + 1 < p.Wo) v = fmaxf(v, vn);
+          v += bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (!(li & 1) && co < p.cout && yy < p.Ho && xx < p.Wo)
+            p.y[((size_t(b) * p.cout + co) * Hp + (yy >> 1)) * Wp + (xx >> 1)] = v;
+        }
+      }
+    }
+  } else if (p.vec_store) {
     float* patch = reinterpret_cast<float*>(smem16) + wave * (32 * 32);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -434,9 +460,9 @@ extern "C" int st_conv3x3_pack_weights_bf16(const float* w_oihw, void* w_packed,
   return st::check_launch("st_conv3x3_pack_weights_bf16");
 }
 
-extern "C" int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* y,
-                                   int n, int cin, int hin, int win, int cout, int upsample2x,
-                                   int pad_mode, int relu, st_stream_t stream) {
+static int conv3x3_fwd_bf16_impl(const float* x, const void* w_packed, const float* bias, float* y,
+                                 int n, int cin, int hin, int win, int cout, int upsample2x,
+                                 int pad_mode, int relu, int pool, st_stream_t stream) {
   ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
              "st_conv3x3_fwd_bf16: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
@@ -449,12 +475,24 @@ extern "C" int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const f
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
   p.up = upsample2x ? 1 : 0;
   p.H = hin << p.up; p.W = win << p.up;
-  p.Ho = p.H; p.Wo = p.W; p.ldo = p.W; p.shift = 0;
+  p.Ho = p.H; p.Wo = p.W; p.ldo = p.W; p.shift = 0; p.pool = pool;
   p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
   p.nchunks = st::cdiv(cin, KC);
   p.pad_zero = pad_mode == ST_PAD_ZERO;
   p.relu = relu ? 1 : 0;
   return dispatch_conv<false>(p, (hipStream_t)stream);
+}
+
+extern "C" int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* y,
+                                   int n, int cin, int hin, int win, int cout, int upsample2x,
+                                   int pad_mode, int relu, st_stream_t stream) {
+  return conv3x3_fwd_bf16_impl(x, w_packed, bias, y, n, cin, hin, win, cout, upsample2x, pad_mode, relu, 0, stream);
+}
+
+extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* ypool,
+                                        int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
+                                        st_stream_t stream) {
+  return conv3x3_fwd_bf16_impl(x, w_packed, bias, ypool, n, cin, hin, win, cout, 0, pad_mode, relu, 1, stream);
 }
 
 extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t,
@@ -480,7 +518,7 @@ extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const
   p.n = n; p.cin = cout; p.hs = h; p.ws = w; p.cout = cin;
   p.up = 0; p.H = h; p.W = w;
   p.Ho = rep ? h + 2 : h; p.Wo = rep ? w + 2 : w; p.shift = rep ? 1 : 0;
-  p.ldo = rep ? st::padded_row(w) : w;
+  p.ldo = rep ? st::padded_row(w) : w; p.pool = 0;
   p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
   p.nchunks = st::cdiv(cout, KC);
   p.pad_zero = 1; p.relu = 0;

@@ -99,8 +99,14 @@ class Encoder(nn.Module):
     def forward(self, x):
         seq = self.encode
         x = conv1x1_apply(x, seq[0].weight, seq[0].bias)
+        frozen = not (torch.is_grad_enabled() and x.requires_grad)
         for idx in self.CONV3:
             conv = seq[idx]
+            if idx in self.POOL_AFTER and frozen:
+                # [pad, conv, ReLU, MaxPool(ceil)] in one launch: the full-resolution activation is never written
+                x = ops.conv3x3_pool(x, self._packed.get(idx, conv.weight, False), conv.bias.detach(),
+                                     int(conv.weight.shape[0]), pad_mode=ops.PAD_REPLICATE, relu=True)
+                continue
             x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=False,
                               pad_mode=ops.PAD_REPLICATE, relu=True)
             if idx in self.POOL_AFTER:

@@ -118,6 +118,29 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     return y
 
 
+def conv3x3_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+                 pad_mode="replicate", relu: bool = True) -> torch.Tensor:
+    """maxpool2x2_ceil(act(bias + conv3x3(pad1(x)))) in one launch (generator.py:51-53, 58-60, 71-73); forward only."""
+    lib = _lib.load()
+    assert x.dim() == 4, "conv3x3_pool expects NCHW"
+    n, cin, h, w = (int(v) for v in x.shape)
+    bf16 = w_packed.dtype == torch.bfloat16
+    need = lib.st_conv3x3_packed_elems_bf16(cout, cin) if bf16 else lib.st_conv3x3_packed_elems(cout, cin)
+    assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} elements, expected {need}"
+    y = torch.empty((n, cout, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device)
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cout, bf16), 2.0 * n * h * w * cin * cout * 9,
+                                 4.0 * (x.numel() + y.numel()))
+    fn = lib.st_conv3x3_pool_fwd_bf16 if bf16 else lib.st_conv3x3_pool_fwd
+    _lib.check(fn(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
+                  _lib.dev_ptr(bias, "bias") if bias is not None else None, _lib.dev_ptr(y, "y"),
+                  n, cin, h, w, cout, _pad_code(pad_mode), int(relu), _lib.stream_ptr()), "st_conv3x3_pool_fwd")
+    if ev is not None:
+        ev.record()
+    return y
+
+
 def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: torch.Tensor, cin: int,
                   upsample2x: bool = False, pad_mode="replicate") -> torch.Tensor:
     """Gradient w.r.t. the input of the fused conv layer; ``y_gate`` = its post-ReLU output (or None)."""

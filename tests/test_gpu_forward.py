@@ -97,3 +97,29 @@ def test_adain_golden(ops, golden_dir):
     mean, std = ops.mean_std(c.cuda(), 1e-5)
     assert rel_err(mean, torch.from_numpy(g["mean"])) < 1e-5
     assert rel_err(std, torch.from_numpy(g["std"])) < 1e-5
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (2, 64, 64, 37, 45),      # odd sizes: ceil-mode windows of one row / one column at the edges
+    (1, 128, 128, 16, 64),
+    (1, 256, 256, 9, 33),
+    (1, 3, 64, 5, 1),         # single column
+    (1, 16, 20, 66, 70),      # ragged channels, several tiles
+])
+def test_conv3x3_fused_ceil_pool(ops, compute, n, cin, cout, h, w):
+    """[pad, conv, ReLU, MaxPool2d(ceil_mode=True)] in one launch (generator.py:51-53) vs conv then pool."""
+    g = torch.Generator().manual_seed(cin + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    with R.conv_compute(compute):
+        ref = torch.nn.functional.max_pool2d(torch.relu(R.conv3x3_padded(R.symmetric_pad(x), wt, b)), 2, 2, 0,
+                                             ceil_mode=True)
+    wp = ops.pack_conv3x3_weights(wt.cuda(), compute=compute)
+    y = ops.conv3x3_pool(x.cuda(), wp, b.cuda(), cout, pad_mode="replicate", relu=True)
+    y2 = ops.maxpool2x2(ops.conv3x3(x.cuda(), wp, b.cuda(), cout, pad_mode="replicate", relu=True), True)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert torch.equal(y, y2)                       # bit-identical to the unfused pair of launches
+    assert rel_err(y, ref) < (1e-5 if compute == "f32" else 1e-4)
