@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.st_version() >= 100
     assert lib.st_conv3x3_packed_elems(64, 3) == 8 * 9 * 128
     assert lib.st_conv3x3_packed_elems(512, 256) == 256 * 9 * 512
-    assert lib.st_conv3x3_dgrad_workspace_bytes(2, 8, 6, 5, 0) == 2 * 8 * 8 * 7 * 4
+    assert lib.st_conv3x3_dgrad_workspace_bytes(2, 8, 6, 5, 0) == 2 * 8 * 8 * 8 * 4     # rows padded 7 -> 8 floats
     assert lib.st_conv3x3_dgrad_workspace_bytes(2, 8, 6, 5, 1) == 0
 
 
