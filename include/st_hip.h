@@ -86,13 +86,16 @@ int st_conv3x3_pool_fwd(const float* x, const float* w_packed, const float* bias
  *   y_gate:  nullable; the layer's post-ReLU output: dy is taken as 0 where y_gate <= 0
  *   w_packed_t: st_conv3x3_pack_weights(..., transpose_flip = 1)
  *   dx:      [n][cin][h/s][w/s], s = 2 if the layer had the fused upsample, else 1
+ *   dx_gate: nullable, same shape as dx (ST_PAD_REPLICATE only): dx is written as 0 where
+ *            dx_gate <= 0 -- the ReLU backward of the layer that PRODUCED this layer's input, fused
+ *            here so that layer's own dgrad / wgrad run without a y_gate (one tensor read less each)
  * ST_PAD_ZERO: one MFMA launch writes dx.  ST_PAD_REPLICATE: the gradient is evaluated on the
  * padded (h+2) x (w+2) domain into `workspace` (st_conv3x3_dgrad_workspace_bytes) and folded
  * back onto the replicated edges (and 2x2-summed for the upsample) by a second launch. */
 size_t st_conv3x3_dgrad_workspace_bytes(int n, int cin, int h, int w, int pad_mode);
 int st_conv3x3_dgrad(const float* dy, const float* y_gate, const float* w_packed_t, float* dx,
-                     float* workspace, int n, int cout, int h, int w, int cin, int upsample2x,
-                     int pad_mode, st_stream_t stream);
+                     float* workspace, const float* dx_gate, int n, int cout, int h, int w, int cin,
+                     int upsample2x, int pad_mode, st_stream_t stream);
 
 /* Weight and bias gradient (decoder training, trainer.py:286-291, 471-473).
  *   x: [n][cin][hin][win] layer input; dy / y_gate: [n][cout][H][W], H = (upsample2x?2:1)*hin
@@ -121,8 +124,8 @@ int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, const float* 
                              st_stream_t stream);
 /* workspace: st_conv3x3_dgrad_workspace_bytes() (same as the fp32 entry point) */
 int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t, float* dx,
-                          float* workspace, int n, int cout, int h, int w, int cin, int upsample2x,
-                          int pad_mode, st_stream_t stream);
+                          float* workspace, const float* dx_gate, int n, int cout, int h, int w, int cin,
+                          int upsample2x, int pad_mode, st_stream_t stream);
 
 /* bf16-operand weight / bias gradient; same arguments, outputs (fp32 dw / dbias) and workspace
  * (st_conv3x3_wgrad_workspace_bytes) as st_conv3x3_wgrad. */

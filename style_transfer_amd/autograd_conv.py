@@ -54,3 +54,56 @@ class MaxPool2x2Function(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         return ops.maxpool2x2_bwd(x, dy.contiguous(), ctx.ceil_mode), None
+
+
+class DecoderChainFunction(torch.autograd.Function):
+    """The whole decoder stack (generator.py:85-130) as ONE autograd node.
+
+    Every intermediate activation has exactly one consumer (the next conv), so the ReLU backward of layer
+    i-1 can be fused into the data-gradient launch of layer i (``dx_gate``): the gradient that reaches layer
+    i-1 is already gated, and its own data-gradient and weight-gradient launches read ``dy`` alone instead of
+    ``dy`` and the saved activation -- one full tensor read less in each of them.
+
+    ``specs``: per layer (key, cout, upsample2x, relu); ``params``: w0, b0, w1, b1, ...
+    """
+
+    @staticmethod
+    def forward(ctx, x, cache, specs, *params):
+        acts = [x]
+        compute = None
+        for i, (key, cout, up, relu) in enumerate(specs):
+            w, b = params[2 * i], params[2 * i + 1]
+            wp = cache.get(key, w, False)
+            compute = "bf16" if wp.dtype == torch.bfloat16 else "f32"
+            acts.append(ops.conv3x3(acts[-1], wp, b.detach(), cout, up, ops.PAD_REPLICATE, relu))
+        ctx.cache, ctx.specs, ctx.compute = cache, specs, compute
+        ctx.save_for_backward(*acts[:-1], *params)          # layer inputs (the last output is not needed)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.specs)
+        saved = ctx.saved_tensors
+        acts, params = saved[:n], saved[n:]
+        g = g.contiguous()
+        grads = [None] * (2 * n)
+        dx = None
+        for i in range(n - 1, -1, -1):
+            key, cout, up, relu = ctx.specs[i]
+            w, b = params[2 * i], params[2 * i + 1]
+            x_i = acts[i]
+            # g = d loss / d (output of layer i); already ReLU-gated by the launch that produced it,
+            # except at the top of the chain, where the layer's own output would be needed -- the
+            # reference's last decoder conv has no ReLU (generator.py:117), which is asserted in Decoder
+            if ctx.needs_input_grad[3 + 2 * i] or ctx.needs_input_grad[4 + 2 * i]:
+                dw, db = ops.conv3x3_wgrad(x_i, g, None, want_bias=True, upsample2x=up,
+                                           pad_mode=ops.PAD_REPLICATE, compute=ctx.compute)
+                grads[2 * i] = dw if ctx.needs_input_grad[3 + 2 * i] else None
+                grads[2 * i + 1] = db if ctx.needs_input_grad[4 + 2 * i] else None
+            if i > 0 or ctx.needs_input_grad[0]:
+                wpt = ctx.cache.get(key, w, True, ctx.compute)
+                gate = x_i if (i > 0 and ctx.specs[i - 1][3]) else None     # input is a ReLU output
+                g = ops.conv3x3_dgrad(g, None, wpt, int(w.shape[1]), up, ops.PAD_REPLICATE, dx_gate=gate)
+                if i == 0:
+                    dx = g
+        return (dx, None, None, *grads)

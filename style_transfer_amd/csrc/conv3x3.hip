@@ -284,7 +284,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // gradient dxp [planes][H+2][W+2]:  dx[i][j] = sum of dxp over every padded position that the
 // forward pass read from source pixel (i, j).
 __global__ __launch_bounds__(256) void dgrad_fold_kernel(const float* __restrict__ dxp,
-                                                        float* __restrict__ dx, int H, int W,
+                                                        float* __restrict__ dx,
+                                                        const float* __restrict__ gate, int H, int W,
                                                         int up, int hs, int ws, long long total) {
   const int Wp = st::padded_row(W);   // row stride of the padded workspace
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void dgrad_fold_kernel(const float* __restrict
     float s = 0.f;
     for (int u = u0; u <= u1; ++u)
       for (int v = v0; v <= v1; ++v) s += src[(size_t)(u + 1) * Wp + (v + 1)];
-    dx[e] = s;
+    // optional fused ReLU backward of the PRODUCER of this layer's input (gate = that activation)
+    dx[e] = (gate && !(gate[e] > 0.f)) ? 0.f : s;
   }
 }
 
@@ -334,11 +336,12 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 namespace st {
 // Adjoint of the replicate pad (+ upsample) on the padded data gradient; shared with the bf16 path.
-int launch_dgrad_fold(const float* dxp, float* dx, int n, int cin, int h, int w, int up, hipStream_t s) {
+int launch_dgrad_fold(const float* dxp, float* dx, const float* gate, int n, int cin, int h, int w, int up,
+                      hipStream_t s) {
   const int hs = h >> up, ws = w >> up;
   const long long total = (long long)n * cin * hs * ws;
   const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 256 * 8);
-  hipLaunchKernelGGL(dgrad_fold_kernel, dim3(blocks), dim3(256), 0, s, dxp, dx, h, w, up, hs, ws, total);
+  hipLaunchKernelGGL(dgrad_fold_kernel, dim3(blocks), dim3(256), 0, s, dxp, dx, gate, h, w, up, hs, ws, total);
   return st::check_launch("st_conv3x3_dgrad(fold)");
 }
 }  // namespace st
@@ -407,8 +410,9 @@ extern "C" size_t st_conv3x3_dgrad_workspace_bytes(int n, int cin, int h, int w,
 }
 
 extern "C" int st_conv3x3_dgrad(const float* dy, const float* y_gate, const float* w_packed_t,
-                                float* dx, float* workspace, int n, int cout, int h, int w,
-                                int cin, int upsample2x, int pad_mode, st_stream_t stream) {
+                                float* dx, float* workspace, const float* dx_gate, int n, int cout,
+                                int h, int w, int cin, int upsample2x, int pad_mode,
+                                st_stream_t stream) {
   ST_REQUIRE(dy && w_packed_t && dx, "st_conv3x3_dgrad: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0,
              "st_conv3x3_dgrad: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
@@ -422,6 +426,7 @@ extern "C" int st_conv3x3_dgrad(const float* dy, const float* y_gate, const floa
   const bool rep = pad_mode == ST_PAD_REPLICATE;
   ST_REQUIRE(!rep || workspace, "st_conv3x3_dgrad: replicate mode needs a workspace of "
              "st_conv3x3_dgrad_workspace_bytes()");
+  ST_REQUIRE(rep || !dx_gate, "st_conv3x3_dgrad: dx_gate is only supported with replicate padding");
   hipStream_t s = (hipStream_t)stream;
   // The data gradient is itself a 3x3 correlation of (gated) dy with the transposed, rotated
   // filter, zero padded.  With edge-replicate forward padding it is evaluated on the padded
@@ -438,5 +443,5 @@ extern "C" int st_conv3x3_dgrad(const float* dy, const float* y_gate, const floa
   p.pad_zero = 1; p.relu = 0;
   int rc = y_gate ? dispatch_conv<true>(p, s) : dispatch_conv<false>(p, s);
   if (rc != ST_OK || !rep) return rc;
-  return st::launch_dgrad_fold(workspace, dx, n, cin, h, w, upsample2x ? 1 : 0, s);
+  return st::launch_dgrad_fold(workspace, dx, dx_gate, n, cin, h, w, upsample2x ? 1 : 0, s);
 }

@@ -433,7 +433,8 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 namespace st {
 // csrc/conv3x3.hip: adjoint of the replicate pad (+ upsample) on the padded data gradient
-int launch_dgrad_fold(const float* dxp, float* dx, int n, int cin, int h, int w, int up, hipStream_t s);
+int launch_dgrad_fold(const float* dxp, float* dx, const float* gate, int n, int cin, int h, int w, int up,
+                      hipStream_t s);
 }  // namespace st
 
 extern "C" size_t st_conv3x3_packed_elems_bf16(int cout, int cin) {
@@ -496,8 +497,9 @@ extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, co
 }
 
 extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t,
-                                     float* dx, float* workspace, int n, int cout, int h, int w,
-                                     int cin, int upsample2x, int pad_mode, st_stream_t stream) {
+                                     float* dx, float* workspace, const float* dx_gate, int n,
+                                     int cout, int h, int w, int cin, int upsample2x, int pad_mode,
+                                     st_stream_t stream) {
   ST_REQUIRE(dy && w_packed_t && dx, "st_conv3x3_dgrad_bf16: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0,
              "st_conv3x3_dgrad_bf16: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
@@ -511,6 +513,7 @@ extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const
   const bool rep = pad_mode == ST_PAD_REPLICATE;
   ST_REQUIRE(!rep || workspace, "st_conv3x3_dgrad_bf16: replicate mode needs a workspace of "
              "st_conv3x3_dgrad_workspace_bytes()");
+  ST_REQUIRE(rep || !dx_gate, "st_conv3x3_dgrad_bf16: dx_gate is only supported with replicate padding");
   hipStream_t s = (hipStream_t)stream;
   ConvParams p;
   p.x = dy; p.gate = y_gate; p.wp = (const u32x4*)w_packed_t; p.bias = nullptr;
@@ -524,5 +527,5 @@ extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const
   p.pad_zero = 1; p.relu = 0;
   int rc = y_gate ? dispatch_conv<true>(p, s) : dispatch_conv<false>(p, s);
   if (rc != ST_OK || !rep) return rc;
-  return st::launch_dgrad_fold(workspace, dx, n, cin, h, w, upsample2x ? 1 : 0, s);
+  return st::launch_dgrad_fold(workspace, dx, dx_gate, n, cin, h, w, upsample2x ? 1 : 0, s);
 }

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, precision
-from .autograd import conv3x3_apply, maxpool2x2_apply, conv1x1_apply, sympad_apply
+from .autograd import _needs_grad, conv3x3_apply, maxpool2x2_apply, conv1x1_apply, sympad_apply
 
 ENCODER_WEIGHTS = r'./src/models/checkpoints/WCT_encoder_decoder/vgg_normalised_conv4_1.pth'   # generator.py:78
 DECODER_WEIGHTS = r"./src/models/checkpoints/WCT_encoder_decoder/feature_invertor_conv4_1.pth"  # generator.py:121
@@ -149,6 +149,16 @@ class Decoder(nn.Module):
 
     def forward(self, x):
         seq = self.decoder
+        params = [t for idx in self.CONV3 for t in (seq[idx].weight, seq[idx].bias)]
+        if _needs_grad(x, *params):
+            # training: the whole stack is one autograd node (fused ReLU backward, autograd_conv.py)
+            from .autograd_conv import DecoderChainFunction
+            specs, up = [], False
+            for idx in self.CONV3:
+                specs.append((idx, int(seq[idx].weight.shape[0]), up, idx != 28))
+                up = idx in self.UP_AFTER
+            assert not specs[-1][3], "the chain backward relies on the last conv having no ReLU"
+            return DecoderChainFunction.apply(x.contiguous(), self._packed, tuple(specs), *params)
         up = False
         for idx in self.CONV3:
             conv = seq[idx]

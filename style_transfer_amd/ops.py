@@ -142,13 +142,17 @@ def conv3x3_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.T
 
 
 def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: torch.Tensor, cin: int,
-                  upsample2x: bool = False, pad_mode="replicate") -> torch.Tensor:
-    """Gradient w.r.t. the input of the fused conv layer; ``y_gate`` = its post-ReLU output (or None)."""
+                  upsample2x: bool = False, pad_mode="replicate",
+                  dx_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient w.r.t. the input of the fused conv layer; ``y_gate`` = its post-ReLU output (or None);
+    ``dx_gate`` (replicate padding only) = the layer's INPUT when that is a ReLU output: the result is
+    zeroed where it is <= 0, i.e. it comes out already gated for the producing layer's backward."""
     lib = _lib.load()
     n, cout, h, w = (int(v) for v in dy.shape)
     pm = _pad_code(pad_mode)
     s = 2 if upsample2x else 1
     dx = torch.empty((n, cin, h // s, w // s), dtype=torch.float32, device=dy.device)
+    assert dx_gate is None or tuple(dx_gate.shape) == tuple(dx.shape), "dx_gate must have the shape of dx"
     nbytes = lib.st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, pm)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device) if nbytes else None
     ev = None
@@ -161,6 +165,7 @@ def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: 
                   _lib.dev_ptr(y_gate, "y_gate") if y_gate is not None else None,
                   _lib.dev_ptr(w_packed_t, "w_packed_t", w_packed_t.dtype), _lib.dev_ptr(dx, "dx"),
                   _lib.dev_ptr(ws, "workspace") if ws is not None else None,
+                  _lib.dev_ptr(dx_gate, "dx_gate") if dx_gate is not None else None,
                   n, cout, h, w, cin, int(upsample2x), pm, _lib.stream_ptr()), "st_conv3x3_dgrad")
     if ev is not None:
         ev.record()

@@ -206,3 +206,52 @@ def test_vincent_loss_golden(golden_dir):
     assert rel_err(cov, torch.from_numpy(g["vincent_cov"])) < 1e-4
     assert float(v) == pytest.approx(float(g["vincent"]), rel=1e-3)
     assert rel_err(a.grad, torch.from_numpy(g["vincent_da"])) < 1e-2     # eigh backward on another LAPACK
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("up", [False, True])
+def test_dgrad_fused_output_gate(compute, up):
+    """dx_gate: the data gradient comes out already masked by the ReLU of the layer that produced the input."""
+    from style_transfer_amd import ops
+    g = torch.Generator().manual_seed(21)
+    n, cin, cout, h, w = 2, 32, 48, 10, 14
+    s = 2 if up else 1
+    x = torch.relu(torch.randn(n, cin, h, w, generator=g)).cuda()        # a ReLU output (about half zeros)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
+    dy = torch.randn(n, cout, h * s, w * s, generator=g).cuda()
+    wpt = ops.pack_conv3x3_weights(wt, transpose_flip=True, compute=compute)
+    plain = ops.conv3x3_dgrad(dy, None, wpt, cin, up, "replicate")
+    gated = ops.conv3x3_dgrad(dy, None, wpt, cin, up, "replicate", dx_gate=x)
+    torch.cuda.synchronize()
+    assert torch.equal(gated, torch.where(x > 0, plain, torch.zeros_like(plain)))
+    with pytest.raises(Exception):
+        ops.conv3x3_dgrad(dy[:, :, :h, :w].contiguous(), None, wpt, cin, False, "zero", dx_gate=x)
+
+
+def test_decoder_chain_matches_per_layer_autograd():
+    """Decoder training backward as one autograd node (fused ReLU backward) vs the per-layer Functions."""
+    from style_transfer_amd import ops
+    from style_transfer_amd.autograd import conv3x3_apply
+    from style_transfer_amd.generator import Decoder
+    dec = Decoder(do_train=True).cuda()
+    dec.load_state_dict(R.make_decoder_state(1))
+    g = torch.Generator().manual_seed(4)
+    t = torch.rand(2, 512, 5, 7, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(2, 3, 40, 56, generator=g).cuda()
+    out = dec(t)
+    out.backward(dy)
+    got = [t.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+    t.grad = None
+    for p in dec.parameters():
+        p.grad = None
+    x, up = t, False
+    for idx in dec.CONV3:                                    # the unfused path: one autograd node per layer
+        conv = dec.decoder[idx]
+        x = conv3x3_apply(x, conv.weight, conv.bias, dec._packed, idx, upsample2x=up, pad_mode=ops.PAD_REPLICATE,
+                          relu=(idx != 28))
+        up = idx in dec.UP_AFTER
+    assert torch.equal(x, out)
+    x.backward(dy)
+    want = [t.grad] + [p.grad for p in dec.parameters()]
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < 1e-5
