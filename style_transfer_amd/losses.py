@@ -332,7 +332,12 @@ class VincentStyleLoss(nn.Module):
         eigroot_mat = self.matrix_diag(torch.sqrt(eigvals.clip(0)))
         root_cov_stl = torch.matmul(torch.matmul(eigvects, eigroot_mat), torch.transpose(eigvects, -1, -2))
         tr_cov_stl = torch.sum(eigvals.clip(0), dim=1, keepdim=True)
-        tr_cov_synth = torch.sum(torch.linalg.eigvalsh(cov_synth).clip(0), dim=1, keepdim=True)
+        # losses.py:73 sums eigvalsh(cov_synth).clip(0).  cov_synth = (x - mu)(x - mu)^T is positive semi-definite by
+        # construction, so that sum IS its trace up to fp32 eigenvalue rounding (<= C * 1e-7 relative, the slightly
+        # negative computed eigenvalues the clip removes); its gradient, the projector onto range(cov_synth), acts
+        # on x - mu exactly like the identity.  Taking the trace saves one of the three batched
+        # eigendecompositions per layer (rocSOLVER: 12 ms for [8, 512, 512]).
+        tr_cov_synth = torch.diagonal(cov_synth, dim1=-2, dim2=-1).sum(dim=1, keepdim=True)
         mean_diff_squared = torch.mean((mean_synth - mean_stl) ** 2)
         cov_prod = torch.matmul(torch.matmul(root_cov_stl, cov_synth), root_cov_stl)
         var_overlap = torch.sum(torch.sqrt(torch.linalg.eigvalsh(cov_prod).clip(0.1)), dim=1, keepdim=True)
