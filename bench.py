@@ -49,9 +49,9 @@ CONTENT_IDX, STYLE_IDX = [21], [2, 7, 14, 19, 25]   # CLI defaults, train.py:80-
 DOMINANT = "conv3x3_f32_kernel<2,2,2,2>"
 DOMINANT_BF16 = "conv3x3_bf16_kernel<2,4,2,4>"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
-# HBM bytes per launch of the dominant kernel from profiles/r1_bench_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
+# HBM bytes per launch of the dominant kernel from profiles/r1_bench_infer_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
 # KiB, averaged over its 20 launches per inference step; 4-B-per-lane loads: FETCH_SIZE taken as reported)
-DOMINANT_TRAFFIC_BYTES = (833662.017 + 298188.8) * 1024
+DOMINANT_TRAFFIC_BYTES = (833426.1 + 298188.8) * 1024
 
 
 def encoder_decoder_flops(side: int):
@@ -224,6 +224,26 @@ def timed(ctx: Ctx, fn, steps: int, warmup: int, collect_kernels: bool):
     return ctx.max_over_ranks(elapsed), records, out
 
 
+def adain_back_to_back(ctx: Ctx, args, reps: int = 20) -> float:
+    """Average duration (us) of the AdaIN launch of one inference step (relu4_1 features of the batch)."""
+    from style_transfer_amd import ops
+    n, c, hw = args.batch, 512, args.side // 8
+    g = torch.Generator(device=ctx.dev).manual_seed(7)
+    sets = [(torch.rand(n, c, hw, hw, device=ctx.dev, generator=g), torch.rand(n, c, hw, hw, device=ctx.dev, generator=g))
+            for _ in range(2)]
+    for fc, fs in sets:
+        ops.adain(fc, fs, 1e-5, 1e-5, 1.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                     # torch's current stream = the stream ops.adain launches on
+    for _ in range(reps):
+        for fc, fs in sets:
+            ops.adain(fc, fs, 1e-5, 1e-5, 1.0)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (2 * reps)
+
+
 def run_inference(ctx: Ctx, args, compute: str = "f32"):
     from oracle import ref_ops as R     # seeded synthetic weights only
     from style_transfer_amd.generator import Decoder, Encoder
@@ -274,7 +294,7 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": round(DOMINANT_TRAFFIC_BYTES) if default_shape else None,
-            "traffic_note": "HBM bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r1_bench_pmc_hbm.csv "
+            "traffic_note": "HBM bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r1_bench_infer_pmc_hbm.csv "
                             "(separate --pmc passes of this command)",
             "kernel": DOMINANT, "launches": len(dom),
             "avg_launch_us": round(secs / max(1, len(dom)) * 1e6, 2),
@@ -286,13 +306,25 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
     ad_bytes = sum(r["bytes"] for r in ad)
     ad_secs = sum(r["ms"] for r in ad) * 1e-3
     ad_gbs = ad_bytes / ad_secs / 1e9 if ad_secs > 0 else 0.0
+    # The in-step figure brackets ONE ~60 us launch with its own event pair (~8 us of event overhead on top of
+    # the kernel); the same launch is therefore also timed back to back, 2 x 20 launches between one event
+    # pair, alternating two feature sets (2 x 402 MB working set >> the 256 MB Infinity Cache: no cache help).
+    b2b_us = adain_back_to_back(ctx, args) if default_shape else None
+    if b2b_us:
+        ad_gbs_step, ad_gbs = ad_gbs, ad_bytes / max(1, len(ad)) / (b2b_us * 1e-6) / 1e9
+    else:
+        ad_gbs_step = ad_gbs
     roof_adain = {"bound": "hbm", "achieved": round(ad_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(ad_gbs / HBM_PEAK_GBS, 4), "kernel": "adain_reg_kernel<4>", "launches": len(ad),
-                  "avg_launch_us": round(ad_secs / max(1, len(ad)) * 1e6, 2),
+                  "avg_launch_us": round(b2b_us, 2) if b2b_us else round(ad_secs / max(1, len(ad)) * 1e6, 2),
+                  "method": "40 launches back to back between one HIP event pair on the launch stream, two "
+                            "alternating feature sets" if b2b_us else "per-launch HIP event pairs inside the timed steps",
+                  "in_step_avg_launch_us": round(ad_secs / max(1, len(ad)) * 1e6, 2),
+                  "in_step_achieved": round(ad_gbs_step, 1),
                   "avg_launch_mbytes": round(ad_bytes / max(1, len(ad)) / 1e6, 2),
                   "traffic": round(ad_bytes / max(1, len(ad))) if default_shape else None,
                   "traffic_note": "PMC: 2 x FETCH_SIZE (gfx950 16-B/lane correction) + WRITE_SIZE = 402.7 MB = "
-                                  "algorithmic bytes (profiles/r1_bench_pmc_hbm.csv)"}
+                                  "algorithmic bytes (profiles/r1_bench_infer_pmc_hbm.csv)"}
     return {
         "metric": "stylized 512x512 img/s (inference)", "value": round(value, 3), "unit": "img/s",
         "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
