@@ -1,0 +1,42 @@
+#!/bin/bash
+# Collects the evidence committed under profiles/ in ONE GPU-box call:
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r1'
+# then copy gpurun_out/prof_r1/* to profiles/r1_*.  Every GPU step has its own time limit; the first
+# failure ends the script (no step runs after a fault or a timeout).
+set -e -o pipefail
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+S=/tmp/prof_scratch_$$ && mkdir -p $S
+
+echo "[1/6] bench line"
+timeout -k 10 420 python3 "$R/bench.py" > "$O/bench_line.json" 2> "$O/bench_line.err"
+
+echo "[2/6] kernel stats, inference legs (fp32 + bf16)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/infer -o p -- \
+    python3 "$R/bench.py" --mode infer --no-cpu-baseline > /dev/null 2> "$O/infer_stats.err"
+cp "$(find $S/infer -name '*kernel_stats.csv' | head -1)" "$O/bench_infer_kernel_stats.csv"
+
+echo "[3/6] kernel stats, fp32 training legs (mean/std + Gram style loss)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/train -o p -- \
+    python3 "$R/bench.py" --mode train --no-bf16 --no-cpu-baseline > /dev/null 2> "$O/train_stats.err"
+cp "$(find $S/train -name '*kernel_stats.csv' | head -1)" "$O/train_step_kernel_stats.csv"
+
+echo "[4/6] kernel stats, bf16 training leg (batch 8 at 512x512)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/trainbf -o p -- \
+    python3 "$R/bench.py" --mode train --compute bf16 --train-side 512 --no-gram --no-bf16 --no-cpu-baseline \
+    > /dev/null 2> "$O/train_bf16_stats.err"
+cp "$(find $S/trainbf -name '*kernel_stats.csv' | head -1)" "$O/train_bf16_512_kernel_stats.csv"
+
+echo "[5/6] PMC pass: FETCH_SIZE"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $S/fetch -o p -- \
+    python3 "$R/bench.py" --mode infer --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> "$O/pmc_fetch.err"
+echo "[6/6] PMC pass: WRITE_SIZE"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $S/write -o p -- \
+    python3 "$R/bench.py" --mode infer --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> "$O/pmc_write.err"
+python3 "$R/tools/pmc_hbm_csv.py" $S/fetch $S/write > "$O/bench_infer_pmc_hbm.csv"
+rm -rf $S
+rm -f "$O"/*.err
+echo done
