@@ -127,6 +127,28 @@ int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_pa
                           float* workspace, const float* dx_gate, int n, int cout, int h, int w, int cin,
                           int upsample2x, int pad_mode, st_stream_t stream);
 
+/* ---- "bf16x3": fp32-grade results from the bf16 matrix pipe ------------------------------------
+ * Same layers, shapes, fp32 NCHW activations and fp32 OIHW master weights as st_conv3x3_fwd /
+ * st_conv3x3_pool_fwd / st_conv3x3_dgrad (generator.py:47-76, 89-117; trainer.py:165-199).  Every fp32
+ * operand v is split exactly into hi = bf16(v), lo = bf16(v - hi) (activations while staged into LDS,
+ * weights when packed) and each product is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation:
+ * three v_mfma_f32_32x32x16_bf16 per product at 16x the fp32 MFMA rate, relative error of a product
+ * < 2^-15 (measured on the 19-conv stylise pipeline: ~1e-5 of the fp32 result; the task's fp32
+ * tolerance is 1e-3).  The packed buffer holds st_conv3x3_packed_elems_bf16x3() 2-byte elements
+ * (hi and lo images), 16-byte aligned. */
+size_t st_conv3x3_packed_elems_bf16x3(int cout, int cin);
+int st_conv3x3_pack_weights_bf16x3(const float* w_oihw, void* w_packed, int cout, int cin,
+                                   int transpose_flip, st_stream_t stream);
+int st_conv3x3_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y,
+                          int n, int cin, int hin, int win, int cout,
+                          int upsample2x, int pad_mode, int relu, st_stream_t stream);
+int st_conv3x3_pool_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* ypool,
+                               int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
+                               st_stream_t stream);
+int st_conv3x3_dgrad_bf16x3(const float* dy, const float* y_gate, const void* w_packed_t, float* dx,
+                            float* workspace, const float* dx_gate, int n, int cout, int h, int w, int cin,
+                            int upsample2x, int pad_mode, st_stream_t stream);
+
 /* bf16-operand weight / bias gradient; same arguments, outputs (fp32 dw / dbias) and workspace
  * (st_conv3x3_wgrad_workspace_bytes) as st_conv3x3_wgrad. */
 int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const float* y_gate, float* dw,

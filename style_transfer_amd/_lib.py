@@ -35,6 +35,14 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_dgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_packed_elems_bf16x3": (c_size_t, [c_int, c_int]),
+    "st_conv3x3_pack_weights_bf16x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_fwd_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_pool_fwd_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_int, c_void_p]),
+    "st_conv3x3_dgrad_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_void_p]),

@@ -19,7 +19,7 @@ class Conv3x3Function(torch.autograd.Function):
         wp = cache.get(key, weight, False)
         y = ops.conv3x3(x, wp, bias.detach() if bias is not None else None, cout, upsample2x, pad_mode, relu)
         ctx.cache, ctx.key = cache, key
-        ctx.compute = "bf16" if wp.dtype == torch.bfloat16 else "f32"   # backward uses the forward's precision
+        ctx.compute = ops.conv_family(wp, int(weight.shape[0]), int(weight.shape[1]))   # backward uses the forward's precision
         ctx.upsample2x, ctx.pad_mode, ctx.relu = upsample2x, pad_mode, relu
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -74,7 +74,7 @@ class DecoderChainFunction(torch.autograd.Function):
         for i, (key, cout, up, relu) in enumerate(specs):
             w, b = params[2 * i], params[2 * i + 1]
             wp = cache.get(key, w, False)
-            compute = "bf16" if wp.dtype == torch.bfloat16 else "f32"
+            compute = ops.conv_family(wp, int(w.shape[0]), int(w.shape[1]))
             acts.append(ops.conv3x3(acts[-1], wp, b.detach(), cout, up, ops.PAD_REPLICATE, relu))
         ctx.cache, ctx.specs, ctx.compute = cache, specs, compute
         ctx.save_for_backward(*acts[:-1], *params)          # layer inputs (the last output is not needed)

@@ -24,6 +24,12 @@
 //     ds_write) into a double buffer: the packed global layout already is the LDS image.
 //   * Both LDS images are double-buffered, one workgroup barrier per chunk; the two waves of a
 //     SIMD run staging and MFMA phases in opposite order (see the schedule comment in the kernel).
+//
+// SPLIT = true is the "bf16x3" mode: fp32-grade results from the bf16 matrix pipe.  Every fp32
+// operand v is split exactly into hi = bf16(v) and lo = bf16(v - hi) (the pair is the same 32 bits
+// as v and carries 16 significand bits), both halves get their own LDS image, and each product is
+// evaluated as hi*hi + hi*lo + lo*hi in the fp32 accumulator (the dropped lo*lo term and the split
+// residuals are < 2^-16 relative).  Three MFMAs per product at 16x the fp32 MFMA rate.
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -62,7 +68,7 @@ struct ConvParams {
   int ablate;              // debug only (ST_BF16_ABLATE): 1 skip MFMA, 2 skip X staging, 4 skip W DMA
 };
 
-template <int MT, int NT, int WM, int WP>
+template <int MT, int NT, int WM, int WP, bool SPLIT = false>
 struct Cfg {
   static constexpr int BM = 32 * MT * WM;
   static constexpr int TH = NT * WP;
@@ -70,10 +76,12 @@ struct Cfg {
   static constexpr int PLANE = HR * HC;          // halo positions
   static constexpr int NITEM = 2 * PLANE;        // (position, channel half) staging items
   static constexpr int NP = (NITEM + NTHREADS - 1) / NTHREADS;
-  static constexpr int W_UNITS = 9 * BM * 2;     // 16-B units of the weight slab
+  static constexpr int NPART = SPLIT ? 2 : 1;    // hi (and lo) images
+  static constexpr int W_UNITS = NPART * 9 * BM * 2;   // 16-B units of the weight slab: [part][tap][BM][2]
   static constexpr int NWI = W_UNITS / 64;        // 1-KiB LDS-DMA wave instructions per weight slab
   static constexpr int NW = (NWI + 7) / 8;        // ... per wave
-  static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + 2 * NITEM) * 16;   // both double-buffered
+  static constexpr int X_UNITS = NPART * NITEM;  // 16-B units of the halo image: [part][position][2]
+  static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + 2 * X_UNITS) * 16;   // both double-buffered
 };
 
 __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
@@ -85,13 +93,13 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
 
 // TAIL: cin is not a multiple of 16 (the 3-channel layers): channel indices are clamped per load
 // and the missing channels masked to zero.
-template <int MT, int NT, int WM, int WP, bool GATE, bool TAIL>
+template <int MT, int NT, int WM, int WP, bool GATE, bool TAIL, bool SPLIT>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p) {
-  using C = Cfg<MT, NT, WM, WP>;
+  using C = Cfg<MT, NT, WM, WP, SPLIT>;
   static_assert(WM * WP == 8, "eight waves per block");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
-  u32x4* Ws = smem16;                     // 2 x [tap][BM][2]   (filled by LDS-DMA)
-  u32x4* Xs = smem16 + 2 * C::W_UNITS;    // 2 x [position][2]
+  u32x4* Ws = smem16;                     // 2 x [part][tap][BM][2]   (filled by LDS-DMA)
+  u32x4* Xs = smem16 + 2 * C::W_UNITS;    // 2 x [part][position][2]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // weights of chunk_ -> W buffer (chunk_ & 1) by LDS-DMA
 #define ST_ISSUE_W(chunk_)                                                                 \
   {                                                                                        \
-    const u32x4* wsrc = p.wp + (size_t(chunk_) * 9 * p.cout_pad + m0) * 2;                 \
+    const u32x4* wsrc = p.wp + (size_t(chunk_) * (9 * C::NPART) * p.cout_pad + m0) * 2;    \
     u32x4* wdst = Ws + ((chunk_) & 1) * C::W_UNITS;                                        \
     _Pragma("unroll") for (int i = 0; i < C::NW; ++i) {                                    \
       const int u = i * 8 + wave;                                                          \
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // registers -> bf16 -> X buffer (chunk_ & 1)
 #define ST_STORE_X(chunk_)                                                                 \
   {                                                                                        \
-    u32x4* xdst = Xs + ((chunk_) & 1) * C::NITEM;                                          \
+    u32x4* xdst = Xs + ((chunk_) & 1) * C::X_UNITS;                                        \
     _Pragma("unroll") for (int i = 0; i < C::NP; ++i) {                                    \
       const int idx = tid + i * NTHREADS;                                                  \
       float v[8];                                                                          \
@@ -206,7 +214,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       }                                                                                    \
       if (C::NITEM % NTHREADS == 0 || idx < C::NITEM) {                                    \
         const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;                     \
-        xdst[pidx * 2 + half] = pack8(v);                                                  \
+        const u32x4 hi = pack8(v);                                                         \
+        xdst[pidx * 2 + half] = hi;                                                        \
+        if (SPLIT) {                                                                       \
+          const bf16x8 hb = __builtin_bit_cast(bf16x8, hi);                                \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] -= float(hb[j]);              \
+          xdst[C::NITEM + pidx * 2 + half] = pack8(v);                                     \
+        }                                                                                  \
       }                                                                                    \
     }                                                                                      \
   }
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #define ST_MFMA(chunk_)                                                                    \
   {                                                                                        \
     const u32x4* aP = aPtr + ((chunk_) & 1) * C::W_UNITS;                                  \
-    const u32x4* bP = bPtr + ((chunk_) & 1) * C::NITEM;                                    \
+    const u32x4* bP = bPtr + ((chunk_) & 1) * C::X_UNITS;                                  \
     _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                  \
       const int dy = tap / 3, dx = tap % 3;                                                \
       bf16x8 a[MT], bb[NT];                                                                \
@@ -223,6 +237,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
           a[mt] = __builtin_bit_cast(bf16x8, aP[(tap * C::BM + mt * 32) * 2]);             \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
           bb[nt] = __builtin_bit_cast(bf16x8, bP[((nt + dy) * HC + dx) * 2]);              \
+      if (SPLIT) {                                                                         \
+        bf16x8 al[MT], bl[NT];                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
+            al[mt] = __builtin_bit_cast(bf16x8, aP[((9 + tap) * C::BM + mt * 32) * 2]);    \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
+            bl[nt] = __builtin_bit_cast(bf16x8, bP[C::NITEM + ((nt + dy) * HC + dx) * 2]); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bb[nt],          \
+                                                                  acc[mt][nt], 0, 0, 0);   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bl[nt],           \
+                                                                  acc[mt][nt], 0, 0, 0);   \
+      }                                                                                    \
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                    \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bb[nt], acc[mt][nt], \
@@ -375,11 +404,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #undef ST_BARRIER_KEEP_LOADS
 #undef ST_BARRIER_DRAIN
 
-// OIHW fp32 -> packed bf16 [cin_pad/16][9][cout_pad][16] (channel innermost: one lane's 8 K values
-// are 16 contiguous bytes).
+// OIHW fp32 -> packed bf16 [cin_pad/16][nparts][9][cout_pad][16] (channel innermost: one lane's 8 K
+// values are 16 contiguous bytes).  nparts = 1: the rounded weight; nparts = 2 (bf16x3 mode): part 0 =
+// hi = bf16(w), part 1 = lo = bf16(w - hi).
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
                                          int O, int I, int flip, int cout, int cin, int cout_pad,
-                                         long long total) {
+                                         int nparts, long long total) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const int c = int(e % KC);
@@ -387,18 +417,22 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __
     const int o = int(k % cout_pad);
     k /= cout_pad;
     const int tap = int(k % 9);
-    const int cg = int(k / 9) * KC + c;
+    k /= 9;
+    const int part = int(k % nparts);
+    const int cg = int(k / nparts) * KC + c;
     float v = 0.f;
     if (o < cout && cg < cin) {
       v = flip ? w[(size_t(cg) * I + o) * 9 + (8 - tap)] : w[(size_t(o) * I + cg) * 9 + tap];
     }
-    wp[e] = (__bf16)v;
+    const __bf16 hi = (__bf16)v;
+    wp[e] = part ? (__bf16)(v - float(hi)) : hi;
   }
 }
 
-template <int MT, int NT, int WM, int WP, bool GATE>
+template <int MT, int NT, int WM, int WP, bool GATE, bool SPLIT = false>
 int launch_conv(ConvParams& p, hipStream_t stream) {
-  using C = Cfg<MT, NT, WM, WP>;
+  using C = Cfg<MT, NT, WM, WP, SPLIT>;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "LDS image exceeds the CU's 160 KB");
   p.tiles_x = st::cdiv(p.Wo, TW);
   p.tiles_y = st::cdiv(p.Ho, C::TH);
   { const char* e = getenv("ST_BF16_ABLATE"); p.ablate = e ? atoi(e) : 0; }
@@ -409,16 +443,18 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   p.vec_store = (p.ldo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
   dim3 grid((unsigned)(ptiles * p.ctiles));
   if (p.cin % KC == 0)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false>), grid, dim3(NTHREADS),
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false, SPLIT>), grid, dim3(NTHREADS),
                        C::LDS_BYTES, stream, p);
   else
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, true>), grid, dim3(NTHREADS),
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, true, SPLIT>), grid, dim3(NTHREADS),
                        C::LDS_BYTES, stream, p);
   return st::check_launch("st_conv3x3_bf16");
 }
 
 template <bool GATE>
-int dispatch_conv(ConvParams& p, hipStream_t s) {
+int dispatch_conv(ConvParams& p, hipStream_t s, bool split = false) {
+  // bf16x3: hi and lo images of both operands -> 64 ch x (16 rows x 32) is the tile that fits LDS
+  if (split) return launch_conv<1, 4, 2, 4, GATE, true>(p, s);
   if (p.cout > 64) return launch_conv<2, 4, 2, 4, GATE>(p, s);   // 128 ch x (16 rows x 32)
   if (p.cout > 32) {
     // the gated (data-gradient) form prefetches twice the registers per staging item: use the
@@ -444,8 +480,12 @@ extern "C" size_t st_conv3x3_packed_elems_bf16(int cout, int cin) {
   return cin_pad * 9 * cout_pad;
 }
 
-extern "C" int st_conv3x3_pack_weights_bf16(const float* w_oihw, void* w_packed, int cout, int cin,
-                                            int transpose_flip, st_stream_t stream) {
+extern "C" size_t st_conv3x3_packed_elems_bf16x3(int cout, int cin) {
+  return 2 * st_conv3x3_packed_elems_bf16(cout, cin);
+}
+
+static int pack_weights_bf16_impl(const float* w_oihw, void* w_packed, int cout, int cin, int transpose_flip,
+                                  int nparts, st_stream_t stream) {
   ST_REQUIRE(w_oihw && w_packed, "st_conv3x3_pack_weights_bf16: null pointer");
   ST_REQUIRE(cout > 0 && cin > 0, "st_conv3x3_pack_weights_bf16: bad dims cout=%d cin=%d", cout, cin);
   ST_REQUIRE(reinterpret_cast<uintptr_t>(w_packed) % 16 == 0,
@@ -453,17 +493,27 @@ extern "C" int st_conv3x3_pack_weights_bf16(const float* w_oihw, void* w_packed,
   const int pc_out = transpose_flip ? cin : cout;
   const int pc_in = transpose_flip ? cout : cin;
   const int cout_pad = st::cdiv(pc_out, CPAD) * CPAD;
-  const long long total = (long long)st_conv3x3_packed_elems_bf16(pc_out, pc_in);
+  const long long total = (long long)st_conv3x3_packed_elems_bf16(pc_out, pc_in) * nparts;
   const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 4096);
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      w_oihw, (__bf16*)w_packed, cout, cin, transpose_flip ? 1 : 0, pc_out, pc_in,
-                     cout_pad, total);
+                     cout_pad, nparts, total);
   return st::check_launch("st_conv3x3_pack_weights_bf16");
+}
+
+extern "C" int st_conv3x3_pack_weights_bf16(const float* w_oihw, void* w_packed, int cout, int cin,
+                                            int transpose_flip, st_stream_t stream) {
+  return pack_weights_bf16_impl(w_oihw, w_packed, cout, cin, transpose_flip, 1, stream);
+}
+
+extern "C" int st_conv3x3_pack_weights_bf16x3(const float* w_oihw, void* w_packed, int cout, int cin,
+                                              int transpose_flip, st_stream_t stream) {
+  return pack_weights_bf16_impl(w_oihw, w_packed, cout, cin, transpose_flip, 2, stream);
 }
 
 static int conv3x3_fwd_bf16_impl(const float* x, const void* w_packed, const float* bias, float* y,
                                  int n, int cin, int hin, int win, int cout, int upsample2x,
-                                 int pad_mode, int relu, int pool, st_stream_t stream) {
+                                 int pad_mode, int relu, int pool, st_stream_t stream, bool split = false) {
   ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
              "st_conv3x3_fwd_bf16: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
@@ -481,7 +531,7 @@ static int conv3x3_fwd_bf16_impl(const float* x, const void* w_packed, const flo
   p.nchunks = st::cdiv(cin, KC);
   p.pad_zero = pad_mode == ST_PAD_ZERO;
   p.relu = relu ? 1 : 0;
-  return dispatch_conv<false>(p, (hipStream_t)stream);
+  return dispatch_conv<false>(p, (hipStream_t)stream, split);
 }
 
 extern "C" int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* y,
@@ -496,10 +546,23 @@ extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, co
   return conv3x3_fwd_bf16_impl(x, w_packed, bias, ypool, n, cin, hin, win, cout, 0, pad_mode, relu, 1, stream);
 }
 
-extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t,
-                                     float* dx, float* workspace, const float* dx_gate, int n,
-                                     int cout, int h, int w, int cin, int upsample2x, int pad_mode,
-                                     st_stream_t stream) {
+extern "C" int st_conv3x3_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y,
+                                     int n, int cin, int hin, int win, int cout, int upsample2x,
+                                     int pad_mode, int relu, st_stream_t stream) {
+  return conv3x3_fwd_bf16_impl(x, w_packed, bias, y, n, cin, hin, win, cout, upsample2x, pad_mode, relu, 0, stream,
+                               true);
+}
+
+extern "C" int st_conv3x3_pool_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* ypool,
+                                          int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
+                                          st_stream_t stream) {
+  return conv3x3_fwd_bf16_impl(x, w_packed, bias, ypool, n, cin, hin, win, cout, 0, pad_mode, relu, 1, stream, true);
+}
+
+static int conv3x3_dgrad_bf16_impl(const float* dy, const float* y_gate, const void* w_packed_t,
+                                   float* dx, float* workspace, const float* dx_gate, int n,
+                                   int cout, int h, int w, int cin, int upsample2x, int pad_mode,
+                                   st_stream_t stream, bool split) {
   ST_REQUIRE(dy && w_packed_t && dx, "st_conv3x3_dgrad_bf16: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0,
              "st_conv3x3_dgrad_bf16: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
@@ -525,7 +588,23 @@ extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const
   p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
   p.nchunks = st::cdiv(cout, KC);
   p.pad_zero = 1; p.relu = 0;
-  int rc = y_gate ? dispatch_conv<true>(p, s) : dispatch_conv<false>(p, s);
+  int rc = y_gate ? dispatch_conv<true>(p, s, split) : dispatch_conv<false>(p, s, split);
   if (rc != ST_OK || !rep) return rc;
   return st::launch_dgrad_fold(workspace, dx, dx_gate, n, cin, h, w, upsample2x ? 1 : 0, s);
+}
+
+extern "C" int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t,
+                                     float* dx, float* workspace, const float* dx_gate, int n,
+                                     int cout, int h, int w, int cin, int upsample2x, int pad_mode,
+                                     st_stream_t stream) {
+  return conv3x3_dgrad_bf16_impl(dy, y_gate, w_packed_t, dx, workspace, dx_gate, n, cout, h, w, cin, upsample2x,
+                                 pad_mode, stream, false);
+}
+
+extern "C" int st_conv3x3_dgrad_bf16x3(const float* dy, const float* y_gate, const void* w_packed_t,
+                                       float* dx, float* workspace, const float* dx_gate, int n,
+                                       int cout, int h, int w, int cin, int upsample2x, int pad_mode,
+                                       st_stream_t stream) {
+  return conv3x3_dgrad_bf16_impl(dy, y_gate, w_packed_t, dx, workspace, dx_gate, n, cout, h, w, cin, upsample2x,
+                                 pad_mode, stream, true);
 }

@@ -40,7 +40,7 @@ def parse_args(args):
     # additions (not in the reference)
     parser.add_argument('--encoder_weights', type=str, default=None,
                         help="vgg_normalised_conv4_1.pth (default: the reference's cwd-relative path)")
-    parser.add_argument('--dtype', choices=["f32", "bf16"], default="f32", help="conv compute precision")
+    parser.add_argument('--dtype', choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")
     args = parser.parse_args(args)
 
     assert os.path.isfile(args.path_to_save_cpkt), "Please provide the .pth file"

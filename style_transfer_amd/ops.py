@@ -51,8 +51,32 @@ class _KernelTimer:
 KERNEL_TIMER = _KernelTimer()
 
 
-def conv_kernel_name(cout: int, bf16: bool = False) -> str:
-    """Template instantiation st_conv3x3_fwd[_bf16] dispatches to (csrc/conv3x3.hip, conv3x3_bf16.hip)."""
+def conv_family(w_packed: torch.Tensor, cout: int, cin: int) -> str:
+    """Kernel family a packed weight buffer belongs to: "f32" (fp32 buffer), "bf16" or "bf16x3" (bf16
+    buffers; the x3 one holds the hi and the lo image, twice the elements).  Checks the size."""
+    lib = _lib.load()
+    if w_packed.dtype == torch.float32:
+        fam, need = "f32", lib.st_conv3x3_packed_elems(cout, cin)
+    else:
+        assert w_packed.dtype == torch.bfloat16, f"packed weights must be fp32 or bf16, got {w_packed.dtype}"
+        need = lib.st_conv3x3_packed_elems_bf16(cout, cin)
+        fam = "bf16"
+        if w_packed.numel() == 2 * need:
+            fam, need = "bf16x3", 2 * need
+    assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} elements, expected {need}"
+    return fam
+
+
+_SUFFIX = {"f32": "", "bf16": "_bf16", "bf16x3": "_bf16x3"}
+
+
+def conv_kernel_name(cout: int, bf16=False) -> str:
+    """Template instantiation st_conv3x3_fwd[_bf16[x3]] dispatches to (csrc/conv3x3.hip, conv3x3_bf16.hip);
+    ``bf16``: bool or a family name."""
+    if bf16 == "bf16x3":
+        return "conv3x3_bf16x3_kernel<1,4,2,4>"
+    if bf16 == "f32":
+        bf16 = False
     if bf16:
         return "conv3x3_bf16_kernel<2,4,2,4>" if cout > 64 else (
             "conv3x3_bf16_kernel<2,4,1,8>" if cout > 32 else "conv3x3_bf16_kernel<1,4,1,8>")
@@ -73,17 +97,19 @@ def _pad_code(pad_mode) -> int:
 def pack_conv3x3_weights(w: torch.Tensor, transpose_flip: bool = False, compute: str = "f32") -> torch.Tensor:
     """OIHW [cout, cin, 3, 3] -> the packed layout st_conv3x3_fwd consumes: K-major fp32 for
     ``compute="f32"``, channel-innermost bf16 for ``compute="bf16"`` (the dtype of the returned
-    tensor selects the kernel family in conv3x3 / conv3x3_dgrad)."""
+    tensor selects the kernel family in conv3x3 / conv3x3_dgrad), hi + lo bf16 images for "bf16x3"."""
     lib = _lib.load()
     assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3, f"expected OIHW 3x3 weights, got {tuple(w.shape)}"
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = w.detach()
     pc_out, pc_in = (cin, cout) if transpose_flip else (cout, cin)
-    if compute == "bf16":
-        packed = torch.empty(lib.st_conv3x3_packed_elems_bf16(pc_out, pc_in), dtype=torch.bfloat16, device=w.device)
-        _lib.check(lib.st_conv3x3_pack_weights_bf16(_lib.dev_ptr(w, "w"), _lib.dev_ptr(packed, "packed", torch.bfloat16),
-                                                    cout, cin, 1 if transpose_flip else 0, _lib.stream_ptr()),
-                   "st_conv3x3_pack_weights_bf16")
+    if compute in ("bf16", "bf16x3"):
+        elems = getattr(lib, "st_conv3x3_packed_elems" + _SUFFIX[compute])
+        pack = getattr(lib, "st_conv3x3_pack_weights" + _SUFFIX[compute])
+        packed = torch.empty(elems(pc_out, pc_in), dtype=torch.bfloat16, device=w.device)
+        _lib.check(pack(_lib.dev_ptr(w, "w"), _lib.dev_ptr(packed, "packed", torch.bfloat16),
+                        cout, cin, 1 if transpose_flip else 0, _lib.stream_ptr()),
+                   "st_conv3x3_pack_weights" + _SUFFIX[compute])
         return packed
     assert compute == "f32", f"unknown compute dtype {compute!r}"
     packed = torch.empty(lib.st_conv3x3_packed_elems(pc_out, pc_in), dtype=torch.float32, device=w.device)
@@ -99,16 +125,14 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     lib = _lib.load()
     assert x.dim() == 4, "conv3x3 expects NCHW"
     n, cin, h, w = (int(v) for v in x.shape)
-    bf16 = w_packed.dtype == torch.bfloat16
-    need = lib.st_conv3x3_packed_elems_bf16(cout, cin) if bf16 else lib.st_conv3x3_packed_elems(cout, cin)
-    assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} elements, expected {need}"
+    bf16 = conv_family(w_packed, cout, cin)
     s = 2 if upsample2x else 1
     y = torch.empty((n, cout, h * s, w * s), dtype=torch.float32, device=x.device)
     ev = None
     if KERNEL_TIMER.enabled:
         ev = KERNEL_TIMER.record(conv_kernel_name(cout, bf16), 2.0 * n * h * s * w * s * cin * cout * 9,
                                  4.0 * (x.numel() + y.numel()))
-    fn = lib.st_conv3x3_fwd_bf16 if bf16 else lib.st_conv3x3_fwd
+    fn = getattr(lib, "st_conv3x3_fwd" + _SUFFIX[bf16])
     _lib.check(fn(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
                   _lib.dev_ptr(bias, "bias") if bias is not None else None,
                   _lib.dev_ptr(y, "y"), n, cin, h, w, cout, int(upsample2x),
@@ -124,15 +148,13 @@ def conv3x3_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.T
     lib = _lib.load()
     assert x.dim() == 4, "conv3x3_pool expects NCHW"
     n, cin, h, w = (int(v) for v in x.shape)
-    bf16 = w_packed.dtype == torch.bfloat16
-    need = lib.st_conv3x3_packed_elems_bf16(cout, cin) if bf16 else lib.st_conv3x3_packed_elems(cout, cin)
-    assert w_packed.numel() == need, f"packed weights have {w_packed.numel()} elements, expected {need}"
+    bf16 = conv_family(w_packed, cout, cin)
     y = torch.empty((n, cout, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device)
     ev = None
     if KERNEL_TIMER.enabled:
         ev = KERNEL_TIMER.record(conv_kernel_name(cout, bf16), 2.0 * n * h * w * cin * cout * 9,
                                  4.0 * (x.numel() + y.numel()))
-    fn = lib.st_conv3x3_pool_fwd_bf16 if bf16 else lib.st_conv3x3_pool_fwd
+    fn = getattr(lib, "st_conv3x3_pool_fwd" + _SUFFIX[bf16])
     _lib.check(fn(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
                   _lib.dev_ptr(bias, "bias") if bias is not None else None, _lib.dev_ptr(y, "y"),
                   n, cin, h, w, cout, _pad_code(pad_mode), int(relu), _lib.stream_ptr()), "st_conv3x3_pool_fwd")
@@ -156,11 +178,11 @@ def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: 
     nbytes = lib.st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, pm)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device) if nbytes else None
     ev = None
-    bf16 = w_packed_t.dtype == torch.bfloat16
+    bf16 = conv_family(w_packed_t, cin, cout)
     if KERNEL_TIMER.enabled:
         ev = KERNEL_TIMER.record(conv_kernel_name(cin, bf16) + " dgrad", 2.0 * n * h * w * cin * cout * 9,
                                  4.0 * (dy.numel() + dx.numel()))
-    fn = lib.st_conv3x3_dgrad_bf16 if bf16 else lib.st_conv3x3_dgrad
+    fn = getattr(lib, "st_conv3x3_dgrad" + _SUFFIX[bf16])
     _lib.check(fn(_lib.dev_ptr(dy, "dy"),
                   _lib.dev_ptr(y_gate, "y_gate") if y_gate is not None else None,
                   _lib.dev_ptr(w_packed_t, "w_packed_t", w_packed_t.dtype), _lib.dev_ptr(dx, "dx"),
@@ -176,7 +198,10 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tens
                   upsample2x: bool = False, pad_mode="replicate",
                   compute: str = "f32") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """(dW [cout,cin,3,3], dbias [cout] or None) of the fused conv layer; ``compute="bf16"`` rounds both
-    GEMM operands (gated dy and the padded input) to bf16, accumulation and outputs stay fp32."""
+    GEMM operands (gated dy and the padded input) to bf16, accumulation and outputs stay fp32;
+    "bf16x3" uses the exact fp32 kernel (precision.py)."""
+    if compute == "bf16x3":
+        compute = "f32"
     lib = _lib.load()
     n, cin, h, w = (int(v) for v in x.shape)
     cout = int(dy.shape[1])

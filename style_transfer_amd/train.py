@@ -82,7 +82,7 @@ def parse_args(args):
     parser.add_argument('--encoder_weights', type=str, default=None, help="vgg_normalised_conv4_1.pth")
     parser.add_argument('--decoder_weights', type=str, default=None, help="feature_invertor_conv4_1.pth")
     parser.add_argument('--vgg_weights', type=str, default=None, help="torchvision vgg19 state dict (vgg19-dcbb9e9d.pth)")
-    parser.add_argument('--dtype', choices=["f32", "bf16"], default="f32", help="conv compute precision")
+    parser.add_argument('--dtype', choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")
     args = parser.parse_args(args)
 
     # Sanity check (train.py:89-99)

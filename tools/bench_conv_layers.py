@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "wgrad"])
-    ap.add_argument("--compute", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16", "bf16x3"])
     args = ap.parse_args()
     dev = torch.device("cuda")
     tot_t = tot_f = 0.0
