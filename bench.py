@@ -48,6 +48,7 @@ TRAIN_BATCH, TRAIN_SIDE = 8, 256  # configs[2]
 CONTENT_IDX, STYLE_IDX = [21], [2, 7, 14, 19, 25]   # CLI defaults, train.py:80-83
 DOMINANT = "conv3x3_f32_kernel<2,2,2,2>"
 DOMINANT_BF16 = "conv3x3_bf16_kernel<2,4,2,4>"
+DOMINANT_BF16X3 = "conv3x3_bf16x3_kernel<1,4,2,4>"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 # HBM bytes per launch of the dominant kernel from profiles/r1_bench_infer_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
 # KiB, averaged over its 20 launches per inference step; 4-B-per-lane loads: FETCH_SIZE taken as reported)
@@ -268,23 +269,30 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
     e_f, d_f = encoder_decoder_flops(args.side)
     per_img = 2 * e_f + d_f
 
-    if compute == "bf16":
-        allconv = [r for r in records if r["kernel"].startswith("conv3x3_bf16_kernel")]
-        dom = [r for r in allconv if r["kernel"] == DOMINANT_BF16]
+    if compute in ("bf16", "bf16x3"):
+        x3 = compute == "bf16x3"
+        dom_name = DOMINANT_BF16X3 if x3 else DOMINANT_BF16
+        allconv = [r for r in records if r["kernel"].startswith("conv3x3_bf16")]
+        dom = [r for r in allconv if r["kernel"] == dom_name]
+        # bf16x3 issues three bf16 MFMAs per algorithmic multiply-add: the matrix pipe does 3x the layer's FLOPs
+        mul = 3.0 if x3 else 1.0
         fl, sec = sum(r["flops"] for r in dom), sum(r["ms"] for r in dom) * 1e-3
-        ach = fl / sec / 1e12 if sec > 0 else 0.0
+        ach = mul * fl / sec / 1e12 if sec > 0 else 0.0
+        what = ("fp32 operands split into hi+lo bf16 halves, 3 bf16 MFMAs per product, fp32 accumulate (fp32-grade: "
+                "~4e-5 max relative error on the pipeline, tests/test_gpu_bf16x3.py)") if x3 else \
+               "bf16 MFMA operands / fp32 accumulate"
         return {"metric": "stylized 512x512 img/s (inference)", "value": round(value, 3), "unit": "img/s",
                 "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "dtype": "bf16",
-                "config": {"workload": f"inference batch {args.batch} at {args.side}x{args.side} per GPU, bf16 MFMA "
-                                       "operands / fp32 accumulate / fp32 NCHW activations", "batch_per_gpu": args.batch,
-                           "side": args.side},
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "dtype": compute,
+                "config": {"workload": f"inference batch {args.batch} at {args.side}x{args.side} per GPU, {what} / "
+                                       "fp32 NCHW activations", "batch_per_gpu": args.batch, "side": args.side},
                 "model_tflops": round(value * per_img / 1e12, 2),
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": DOMINANT_BF16,
+                             "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": dom_name,
+                             "mfma_flops_per_algorithmic_flop": mul,
                              "launches": len(dom), "avg_launch_us": round(sec / max(1, len(dom)) * 1e6, 2),
-                             "all_conv_tflops": round(sum(r["flops"] for r in allconv) /
-                                                      max(1e-12, sum(r["ms"] for r in allconv) * 1e-3) / 1e12, 1)}}
+                             "all_conv_tflops_algorithmic": round(sum(r["flops"] for r in allconv) /
+                                                                  max(1e-12, sum(r["ms"] for r in allconv) * 1e-3) / 1e12, 1)}}
     dom = [r for r in records if r["kernel"] == DOMINANT]
     allconv = [r for r in records if r["kernel"].startswith("conv3x3_f32_kernel")]
     flops = sum(r["flops"] for r in dom)
@@ -406,9 +414,10 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--no-gram", action="store_true", help="skip the VincentStyleLoss variant of the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--compute", choices=["f32", "bf16", "bf16x3"], default="f32",
                     help="conv compute precision of the main legs (profiling aid; the headline legs are f32)")
-    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 compute-mode legs (BASELINE configs[3] shape)")
+    ap.add_argument("--no-bf16", action="store_true",
+                    help="skip the bf16 (BASELINE configs[3] shape) and bf16x3 compute-mode legs")
     args = ap.parse_args()
     if os.environ.get("ST_BENCH_WATCHDOG"):      # dump every thread's stack and exit if the run hangs
         import faulthandler
@@ -436,6 +445,14 @@ def main():
             bf["train"] = run_train(ctx, args, use_vincent=False, compute="bf16", batch=8, side=512)
             bf["train"]["config"]["workload"] = "BASELINE configs[3] per-GPU shape: " + bf["train"]["config"]["workload"]
         line["bf16"] = bf
+        # fp32-grade results from the bf16 matrix pipe (hi+lo operand split, 3 MFMAs per product); same shapes as
+        # the headline legs (configs[1] inference, configs[2] training; weight gradient on the exact fp32 kernel)
+        x3 = {}
+        if args.mode in ("both", "infer"):
+            x3["inference"] = run_inference(ctx, args, compute="bf16x3")
+        if args.mode in ("both", "train"):
+            x3["train"] = run_train(ctx, args, use_vincent=False, compute="bf16x3")
+        line["bf16x3"] = x3
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline:
             if args.mode in ("both", "infer"):

@@ -13,9 +13,13 @@
 //   * M (accumulator registers) = output channels, N (lanes) = 32 consecutive x of one output row:
 //     an accumulator register is an NCHW row segment, stores are full 128-B lines.
 //   * K step of one MFMA = 16 input channels of one tap.  A lane supplies 8 consecutive channels
-//     of its row/column, so both LDS images are channel-innermost: X halo [(TH+2)*34 positions][16 ch]
-//     and W slab [9 taps][BM cout][16 ch], and every operand is ONE conflict-free ds_read_b128
-//     (64 lanes x 16 B contiguous).
+//     of its row/column (lanes 0-31: channels 0-7, lanes 32-63: channels 8-15), so both LDS images
+//     keep 8 channels innermost with the channel half as the OUTER index: X halo
+//     [2 halves][(TH+2)*34 positions][8 ch] and W slab [9 taps][2 halves][BM cout][8 ch].  Every
+//     operand is ONE ds_read_b128 whose two 32-lane halves each read 512 contiguous bytes: the
+//     16-lane service groups of ds_read_b128 never mix the halves, so the read is conflict-free
+//     (a [position][16 ch] image, lanes at 32-B stride, is a 2-way conflict in every group and
+//     made the LDS array, not the matrix pipe, the limiter: 0.75 reads per MFMA x 8 cycles x 4 SIMDs).
 //   * Staging transposes NCHW -> channel-innermost for free: a thread loads the same halo position
 //     of 8 channels (8 coalesced dword loads across the wave), packs them to 8 bf16 and issues one
 //     ds_write_b128.  Edge replicate / zero pad / upsample source index are resolved in the
@@ -52,7 +56,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvParams {
   const float* x;
   const float* gate;       // GATE kernels: same shape as x; x is read as 0 where gate <= 0
-  const u32x4* wp;         // packed bf16 weights, 16-B units: [chunk][tap][cout_pad][2]
+  const u32x4* wp;         // packed bf16 weights, 16-B units: [chunk][part][tap][half][cout_pad]
   const float* bias;
   float* y;
   int n, cin, hs, ws;      // source tensor dims
@@ -77,10 +81,10 @@ struct Cfg {
   static constexpr int NITEM = 2 * PLANE;        // (position, channel half) staging items
   static constexpr int NP = (NITEM + NTHREADS - 1) / NTHREADS;
   static constexpr int NPART = SPLIT ? 2 : 1;    // hi (and lo) images
-  static constexpr int W_UNITS = NPART * 9 * BM * 2;   // 16-B units of the weight slab: [part][tap][BM][2]
+  static constexpr int W_UNITS = NPART * 9 * BM * 2;   // 16-B units of the weight slab: [part][tap][half][BM]
   static constexpr int NWI = W_UNITS / 64;        // 1-KiB LDS-DMA wave instructions per weight slab
   static constexpr int NW = (NWI + 7) / 8;        // ... per wave
-  static constexpr int X_UNITS = NPART * NITEM;  // 16-B units of the halo image: [part][position][2]
+  static constexpr int X_UNITS = NPART * NITEM;  // 16-B units of the halo image: [part][half][position]
   static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + 2 * X_UNITS) * 16;   // both double-buffered
 };
 
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   using C = Cfg<MT, NT, WM, WP, SPLIT>;
   static_assert(WM * WP == 8, "eight waves per block");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
-  u32x4* Ws = smem16;                     // 2 x [part][tap][BM][2]   (filled by LDS-DMA)
-  u32x4* Xs = smem16 + 2 * C::W_UNITS;    // 2 x [part][position][2]
+  u32x4* Ws = smem16;                     // 2 x [part][tap][half][BM]   (filled by LDS-DMA)
+  u32x4* Xs = smem16 + 2 * C::W_UNITS;    // 2 x [part][half][position]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -159,15 +163,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #pragma unroll
   for (int i = 0; i < C::NW; ++i) {
     const int e = min(i * 8 + wave, C::NWI - 1) * 64 + lane;
-    const int tap = e / (C::BM * 2), r = e - tap * (C::BM * 2);
-    woff[i] = unsigned(tap) * unsigned(p.cout_pad) * 2u + unsigned(r);
+    const int th = e / C::BM, r = e - th * C::BM;      // th = (part * 9 + tap) * 2 + half
+    woff[i] = unsigned(th) * unsigned(p.cout_pad) + unsigned(r);
   }
 
   // ---- staging macros ----------------------------------------------------------------------
   // weights of chunk_ -> W buffer (chunk_ & 1) by LDS-DMA
 #define ST_ISSUE_W(chunk_)                                                                 \
   {                                                                                        \
-    const u32x4* wsrc = p.wp + (size_t(chunk_) * (9 * C::NPART) * p.cout_pad + m0) * 2;    \
+    const u32x4* wsrc = p.wp + size_t(chunk_) * (18 * C::NPART) * p.cout_pad + m0;         \
     u32x4* wdst = Ws + ((chunk_) & 1) * C::W_UNITS;                                        \
     _Pragma("unroll") for (int i = 0; i < C::NW; ++i) {                                    \
       const int u = i * 8 + wave;                                                          \
@@ -213,13 +217,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         v[j] = __uint_as_float(__float_as_uint(xr[i][j]) & m);                             \
       }                                                                                    \
       if (C::NITEM % NTHREADS == 0 || idx < C::NITEM) {                                    \
-        const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;                     \
         const u32x4 hi = pack8(v);                                                         \
-        xdst[pidx * 2 + half] = hi;                                                        \
+        xdst[idx] = hi;               /* idx = half * PLANE + position */                  \
         if (SPLIT) {                                                                       \
           const bf16x8 hb = __builtin_bit_cast(bf16x8, hi);                                \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] -= float(hb[j]);              \
-          xdst[C::NITEM + pidx * 2 + half] = pack8(v);                                     \
+          xdst[C::NITEM + idx] = pack8(v);                                                 \
         }                                                                                  \
       }                                                                                    \
     }                                                                                      \
@@ -234,15 +237,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       const int dy = tap / 3, dx = tap % 3;                                                \
       bf16x8 a[MT], bb[NT];                                                                \
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                    \
-          a[mt] = __builtin_bit_cast(bf16x8, aP[(tap * C::BM + mt * 32) * 2]);             \
+          a[mt] = __builtin_bit_cast(bf16x8, aP[tap * 2 * C::BM + mt * 32]);               \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
-          bb[nt] = __builtin_bit_cast(bf16x8, bP[((nt + dy) * HC + dx) * 2]);              \
+          bb[nt] = __builtin_bit_cast(bf16x8, bP[(nt + dy) * HC + dx]);                    \
       if (SPLIT) {                                                                         \
         bf16x8 al[MT], bl[NT];                                                             \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
-            al[mt] = __builtin_bit_cast(bf16x8, aP[((9 + tap) * C::BM + mt * 32) * 2]);    \
+            al[mt] = __builtin_bit_cast(bf16x8, aP[(9 + tap) * 2 * C::BM + mt * 32]);      \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
-            bl[nt] = __builtin_bit_cast(bf16x8, bP[C::NITEM + ((nt + dy) * HC + dx) * 2]); \
+            bl[nt] = __builtin_bit_cast(bf16x8, bP[C::NITEM + (nt + dy) * HC + dx]);       \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
           _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                \
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bb[nt],          \
@@ -276,8 +279,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const u32x4* aPtr = Ws + (wm * (MT * 32) + li) * 2 + lh;
-  const u32x4* bPtr = Xs + ((wp * NT) * HC + li) * 2 + lh;
+  const u32x4* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li;
+  const u32x4* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li;
 
   // Schedule (X and W double-buffered in LDS, ONE barrier per chunk).  In iteration c every wave
   // issues the LDS-DMA of W(c+1), converts/stores X(c+1) from the registers loaded one iteration
@@ -404,22 +407,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #undef ST_BARRIER_KEEP_LOADS
 #undef ST_BARRIER_DRAIN
 
-// OIHW fp32 -> packed bf16 [cin_pad/16][nparts][9][cout_pad][16] (channel innermost: one lane's 8 K
-// values are 16 contiguous bytes).  nparts = 1: the rounded weight; nparts = 2 (bf16x3 mode): part 0 =
+// OIHW fp32 -> packed bf16 [cin_pad/16][nparts][9][2 halves][cout_pad][8] (8 channels innermost: one
+// lane's 8 K values are 16 contiguous bytes; the channel half outside cout: the LDS image of a block).  nparts = 1: the rounded weight; nparts = 2 (bf16x3 mode): part 0 =
 // hi = bf16(w), part 1 = lo = bf16(w - hi).
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
                                          int O, int I, int flip, int cout, int cin, int cout_pad,
                                          int nparts, long long total) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
-    const int c = int(e % KC);
-    long long k = e / KC;
+    const int c = int(e % 8);
+    long long k = e / 8;
     const int o = int(k % cout_pad);
     k /= cout_pad;
+    const int half = int(k % 2);
+    k /= 2;
     const int tap = int(k % 9);
     k /= 9;
     const int part = int(k % nparts);
-    const int cg = int(k / nparts) * KC + c;
+    const int cg = int(k / nparts) * KC + half * 8 + c;
     float v = 0.f;
     if (o < cout && cg < cin) {
       v = flip ? w[(size_t(cg) * I + o) * 9 + (8 - tap)] : w[(size_t(o) * I + cg) * 9 + tap];
