@@ -18,11 +18,15 @@ BASELINE.json's metric has two halves and rank 0 prints ONE JSON line carrying b
 
 Extra objects (task brief, section 4):
   roofline     -- the dominant kernel (fp32 MFMA conv3x3, 128-channel tile instantiation): algorithmic
-                  FLOPs per launch / average launch duration, measured with HIP events on the launch
-                  stream inside the timed region; `traffic` = HBM bytes per launch from the committed
-                  PMC passes (profiles/, FETCH_SIZE + WRITE_SIZE), not collected live.
+                  FLOPs per launch / average launch duration, measured live with a HIP event pair around
+                  every launch on the launch stream, over a repeat of the K timed steps run right after the
+                  timed region (inside it the event packets open launch gaps on some boxes: 284-305 vs a
+                  steady 308 img/s, same kernel durations); `traffic` = HBM bytes per launch from the
+                  committed PMC passes (profiles/, FETCH_SIZE + WRITE_SIZE), not collected live.
   roofline_adain -- the HBM-bound AdaIN kernel: algorithmic bytes (read content, read style, write
-                  out) / average launch duration against the 8 TB/s HBM3E peak.
+                  out) / average launch duration against the 8 TB/s HBM3E peak; 40 launches back to back
+                  between one event pair on two alternating feature sets (nothing cached), the in-step
+                  per-launch figure next to it.
   cpu_baseline -- the CPU oracle (oracle/ref_ops.py, a port of the reference's torch path) timed on
                   this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -209,20 +213,30 @@ def timed(ctx: Ctx, fn, steps: int, warmup: int, collect_kernels: bool):
     for _ in range(warmup):
         fn()
     ctx.barrier()
-    collect_kernels = collect_kernels and not os.environ.get("ST_NO_KTIMER")
-    if collect_kernels:
-        ops.KERNEL_TIMER.start()
-        fn()                                             # untimed: count the launches of one step
-        per_step = len(ops.KERNEL_TIMER.stop())
-        ctx.barrier()
-        ops.KERNEL_TIMER.start(prealloc=per_step * steps)   # events created outside the timed region
     t0 = time.perf_counter()
     for _ in range(steps):
         out = fn()
     ctx.barrier()
-    elapsed = time.perf_counter() - t0
-    records = ops.KERNEL_TIMER.stop() if collect_kernels else []
-    return ctx.max_over_ranks(elapsed), records, out
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    # Per-launch HIP events for the roofline objects: the SAME K steps are run once more, right after the
+    # timed region, with an event pair around every launch on the launch stream.  They are not recorded
+    # inside the timed region itself because the event packets open gaps between launches on some boxes
+    # (measured: 308 img/s without them, 284-305 img/s with them, kernel durations identical); the step time
+    # of the instrumented repeat is reported next to the clean one.
+    records, elapsed_ev = [], None
+    if collect_kernels and not os.environ.get("ST_NO_KTIMER"):
+        ops.KERNEL_TIMER.start()
+        fn()                                             # count the launches of one step
+        per_step = len(ops.KERNEL_TIMER.stop())
+        ctx.barrier()
+        ops.KERNEL_TIMER.start(prealloc=per_step * steps)   # events created before the loop
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        ctx.barrier()
+        elapsed_ev = time.perf_counter() - t0
+        records = ops.KERNEL_TIMER.stop()
+    return elapsed, records, out, elapsed_ev
 
 
 def adain_back_to_back(ctx: Ctx, args, reps: int = 20) -> float:
@@ -262,8 +276,9 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
 
     from style_transfer_amd import precision
     with precision.compute_dtype(compute):
-        elapsed, records, out = timed(ctx, lambda: stylize(enc, dec, ada, content, style, alpha=1.0),
-                                      args.steps, args.warmup, collect_kernels=True)
+        elapsed, records, out, elapsed_ev = timed(ctx, lambda: stylize(enc, dec, ada, content, style, alpha=1.0),
+                                                  args.steps, args.warmup, collect_kernels=True)
+    elapsed_ev = elapsed_ev or elapsed
     assert torch.isfinite(out).all()
     value = ctx.world * args.batch * args.steps / elapsed
     e_f, d_f = encoder_decoder_flops(args.side)
@@ -309,7 +324,10 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
             "avg_launch_gflop": round(flops / max(1, len(dom)) / 1e9, 3),
             "all_conv_tflops": round(sum(r["flops"] for r in allconv) /
                                      max(1e-12, sum(r["ms"] for r in allconv) * 1e-3) / 1e12, 2),
-            "all_conv_time_frac_of_step": round(sum(r["ms"] for r in allconv) * 1e-3 / elapsed, 4)}
+            "all_conv_time_frac_of_step": round(sum(r["ms"] for r in allconv) * 1e-3 / elapsed, 4),
+            "method": "HIP event pair around every launch on the launch stream, over a repeat of the K timed "
+                      "steps run right after them (events inside the timed region open launch gaps on some boxes)",
+            "ms_per_step_instrumented": round(elapsed_ev / args.steps * 1e3, 3)}
     ad = [r for r in records if r["kernel"].startswith("adain")]
     ad_bytes = sum(r["bytes"] for r in ad)
     ad_secs = sum(r["ms"] for r in ad) * 1e-3
@@ -380,7 +398,7 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
     from style_transfer_amd import precision
     steps, warmup = args.train_steps, args.train_warmup
     with precision.compute_dtype(compute):
-        elapsed, _, losses = timed(ctx, one, steps, warmup, collect_kernels=False)
+        elapsed, _, losses, _ = timed(ctx, one, steps, warmup, collect_kernels=False)
     total = float(losses[4].detach())
     assert total == total, "training loss is NaN"
     value = ctx.world * tb * steps / elapsed

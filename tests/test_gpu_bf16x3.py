@@ -95,7 +95,7 @@ def test_stylize_bf16x3_pipeline():
 
 def test_train_step_bf16x3_matches_fp32():
     """Training step in bf16x3 mode vs the exact-fp32 HIP path: every loss within 1e-3 relative, decoder
-    gradients of the content / style / variation terms within 1e-2 relative L2 per parameter (forward and data
+    gradients of the content / style terms within 1e-2 (variation: 5e-2) relative L2 per parameter (forward and data
     gradient on the split kernels, weight gradient on the fp32 kernel; isolated ReLU gates may flip where a
     pre-activation is within 1e-5 of zero).  The histogram term's gradient is left out for the reason given in
     tests/test_gpu_bf16.py (discontinuous clamp mask)."""
@@ -123,4 +123,6 @@ def test_train_step_bf16x3_matches_fp32():
         for (pname, _), a, b in zip(params, gx3, g32):
             if name == "variation" and pname.endswith("28.bias"):
                 continue                                     # analytically zero
-            assert rel_l2(a, b) < 1e-2, (name, pname, rel_l2(a, b))
+            # TVLoss' gradient is sign(difference) (losses.py:104-116): a 1e-5 perturbation of the decoded image
+            # flips the sign wherever neighbouring pixels are that close, so that term gets a wider bar
+            assert rel_l2(a, b) < (5e-2 if name == "variation" else 1e-2), (name, pname, rel_l2(a, b))
