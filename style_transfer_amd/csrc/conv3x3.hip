@@ -335,6 +335,9 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 }  // namespace
 
 namespace st {
+// csrc/conv3x3_small.hip: vector-ALU kernels for the 3-channel layers
+bool conv3x3_small_fwd(const float* x, const float* w_packed, const float* bias, float* y, int n, int cin,
+                       int h, int w, int cout, int cout_pad, int pad_zero, int relu, hipStream_t s, int* rc);
 // Adjoint of the replicate pad (+ upsample) on the padded data gradient; shared with the bf16 path.
 int launch_dgrad_fold(const float* dxp, float* dx, const float* gate, int n, int cin, int h, int w, int up,
                       hipStream_t s) {
@@ -379,6 +382,14 @@ static int conv3x3_fwd_impl(const float* x, const float* w_packed, const float* 
              "st_conv3x3_fwd: bad pad_mode %d", pad_mode);
   ST_REQUIRE((long long)hin * win * (upsample2x ? 4 : 1) < (1LL << 31),
              "st_conv3x3_fwd: plane too large");
+  if (!upsample2x && !pool) {
+    // the 3-channel layers (conv1_1, last decoder conv) are HBM-bound: vector-ALU kernels, no MFMA padding
+    static const bool no_small = getenv("ST_NO_SMALL_CONV") != nullptr;     // A/B switch for benchmarking
+    int rc = ST_OK;
+    if (!no_small && st::conv3x3_small_fwd(x, w_packed, bias, y, n, cin, hin, win, cout, st::cdiv(cout, CPAD) * CPAD,
+                                           pad_mode == ST_PAD_ZERO, relu ? 1 : 0, (hipStream_t)stream, &rc))
+      return rc;
+  }
   ConvParams p;
   p.x = x; p.gate = nullptr; p.wp = w_packed; p.bias = bias; p.y = y;
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;

@@ -1,0 +1,250 @@
+// The two 3-channel layers of the generator on the vector ALU (gfx950): conv1_1 (3 -> 64,
+// generator.py:47-49; also the loss VGG's first conv, trainer.py:165-199) and the decoder's last
+// conv (64 -> 3, generator.py:115-117).
+//
+// On the MFMA kernels of csrc/conv3x3.hip these layers pad K (3 -> 8 input channels) or M
+// (3 -> 32 output channels) and run MFMA-bound on the padding: 0.64 ms and 1.29 ms at batch 16,
+// 512x512 for 14.5 GFLOP each.  Their real bound is HBM (1.07 GB written / read, ~0.2 ms), and the
+// 7.2 G FMAs fit the vector ALU in about the same time, so they are plain fp32 FMA kernels:
+//   * weights are staged once per block into LDS from the packed layout of st_conv3x3_pack_weights
+//     ([cin/8][9 taps][8][cout_pad]) and read with broadcast 16-B LDS loads;
+//   * cin_small: one thread = two output pixels, their 2 x 27 inputs in registers, output channels in
+//     groups of 16 accumulators per pixel; stores are 128-B row segments;
+//   * cout_small: one thread = 4 consecutive pixels x 3 output channels; per chunk of 8 input
+//     channels the (16+2) x (64+2) halo is staged in LDS (edge replicate / zero pad resolved in
+//     per-thread offsets computed once), rows are read as one 16-B + one 8-B LDS load.
+// Same semantics and boundary as st_conv3x3_fwd (fp32 NCHW in / out, bias, optional ReLU); used by
+// it transparently when the shape fits (no upsample, no fused pool).
+#include <algorithm>
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 8;
+
+// ---- cin == 3, cout <= 64 ---------------------------------------------------------------
+// Weights go through LDS ([27 steps][64 couts], 6.9 KB, staged once per block) and are read with
+// broadcast ds_read_b128 (every lane the same address); a thread owns TWO pixels (rows r and r+8 of a
+// 16 x 32 tile) so that each weight read feeds two FMAs and the LDS pipe stays at half load.
+// (Wave-uniform global loads would be the natural form, but the compiler turns 27 x 16 of them into
+// vector loads + v_readlane and spills SGPRs.)
+constexpr int ACO = 64;      // output channels held in the LDS weight image
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, int H, int W, int cout, int cout_pad, int pad_zero, int relu,
+    int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * ACO];
+  __shared__ float bs[ACO];
+  int bt = blockIdx.x;
+  const int tx = bt % tiles_x;
+  bt /= tiles_x;
+  const int ty = bt % tiles_y;
+  const int b = bt / tiles_y;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < CIN * 9 * ACO; i += 256) {
+    const int step = i / ACO, co = i - step * ACO;       // step = c * 9 + tap
+    const int c = step / 9, tap = step - c * 9;
+    ws[i] = co < cout ? wp[size_t(tap * KC + c) * cout_pad + co] : 0.f;
+  }
+  if (tid < ACO) bs[tid] = (bias && tid < cout) ? bias[tid] : 0.f;
+
+  // Pixels past the right / bottom edge are clamped onto the edge pixel: such a thread recomputes that
+  // pixel and stores the identical value (no branch around the stores: LLVM would sink the FMA chains into it).
+  const int ox = min(tx * 32 + (tid & 31), W - 1);
+  const size_t plane = size_t(H) * W;
+  const float* xb = x + size_t(b) * CIN * plane;
+  float in[2][CIN * 9];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int oy = min(ty * 16 + (tid >> 5) + 8 * p, H - 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int gy = oy + tap / 3 - 1, gx = ox + tap % 3 - 1;
+      const bool keep = (gy >= 0 && gy < H && gx >= 0 && gx < W) || !pad_zero;
+      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        const float v = xb[c * plane + size_t(cy) * W + cx];
+        in[p][c * 9 + tap] = keep ? v : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int co0 = 0; co0 < cout; co0 += 16) {
+    float acc[2][16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[0][k] = acc[1][k] = bs[co0 + k];
+#pragma unroll
+    for (int step = 0; step < CIN * 9; ++step) {
+      float wv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(ws + step * ACO + co0 + q * 4);
+        wv[q * 4 + 0] = t.x; wv[q * 4 + 1] = t.y; wv[q * 4 + 2] = t.z; wv[q * 4 + 3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        acc[0][k] = fmaf(wv[k], in[0][step], acc[0][k]);
+        acc[1][k] = fmaf(wv[k], in[1][step], acc[1][k]);
+      }
+      // compiler fence: without it all 108 weight reads of the group are hoisted above the FMAs and spill
+      if (step % 3 == 2) asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int oy = min(ty * 16 + (tid >> 5) + 8 * p, H - 1);
+      float* yb = y + size_t(b) * cout * plane + size_t(oy) * W + ox;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {        // cout % 16 == 0 (host check): no per-channel branch either
+        float v = acc[p][k];
+        if (relu) v = fmaxf(v, 0.f);
+        yb[size_t(co0 + k) * plane] = v;
+      }
+    }
+  }
+}
+
+// ---- cout <= 4 (cin % 8 == 0) -----------------------------------------------------------
+constexpr int BTH = 16, BTW = 64;                 // output tile of a block
+constexpr int BHR = BTH + 2, BHC = BTW + 2;       // halo
+constexpr int BLD = 68;                           // LDS row stride (floats): 16-B aligned rows
+constexpr int BNP = (BHR * BHC + 255) / 256;      // halo positions per thread
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, int cin, int H, int W, int cout_pad, int pad_zero, int relu,
+    int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float xs[KC * BHR * BLD];
+  extern __shared__ __attribute__((aligned(16))) float wsm[];     // [cin * 9][4]: (co 0..2, pad) per (channel, tap)
+  int bt = blockIdx.x;
+  const int tx = bt % tiles_x;
+  bt /= tiles_x;
+  const int ty = bt % tiles_y;
+  const int b = bt / tiles_y;
+  const int tid = threadIdx.x;
+  const int x0 = tx * BTW, y0 = ty * BTH;
+  const size_t plane = size_t(H) * W;
+  const float* xb = x + size_t(b) * cin * plane;
+
+  // staging positions of this thread (source offset inside a plane, LDS offset, zero-pad mask)
+  unsigned soff[BNP], loff[BNP], smask[BNP];
+#pragma unroll
+  for (int i = 0; i < BNP; ++i) {
+    const int idx = min(tid + i * 256, BHR * BHC - 1);
+    const int r = idx / BHC, cc = idx - r * BHC;
+    const int gy = y0 + r - 1, gx = x0 + cc - 1;
+    const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+    soff[i] = unsigned(cy) * unsigned(W) + unsigned(cx);
+    loff[i] = unsigned(r * BLD + cc);
+    smask[i] = (inb || !pad_zero) ? 0xffffffffu : 0u;
+  }
+
+  for (int i = tid; i < cin * 9 * 4; i += 256) {
+    const int o = i & 3, ct = i >> 2;                  // ct = channel * 9 + tap
+    const int c = ct / 9, tap = ct - c * 9;
+    wsm[i] = o < CO ? wp[size_t(((c / KC) * 9 + tap) * KC + (c % KC)) * cout_pad + o] : 0.f;
+  }
+  const int row = tid >> 4, col4 = (tid & 15) * 4;    // 16 rows x 16 groups of 4 pixels
+  float acc[CO][4];
+#pragma unroll
+  for (int o = 0; o < CO; ++o)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[o][q] = bias ? bias[o] : 0.f;
+
+  const int nchunks = cin / KC;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    float st_[KC][BNP];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const float* src = xb + size_t(chunk * KC + c) * plane;
+#pragma unroll
+      for (int i = 0; i < BNP; ++i) st_[c][i] = src[soff[i]];
+    }
+    __syncthreads();                                  // previous chunk's reads are done
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int i = 0; i < BNP; ++i)
+        if (BHR * BHC % 256 == 0 || tid + i * 256 < BHR * BHC)
+          xs[c * (BHR * BLD) + loff[i]] = __uint_as_float(__float_as_uint(st_[c][i]) & smask[i]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      float v[3][6];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* rp = xs + c * (BHR * BLD) + (row + dy) * BLD + col4;
+        const float4 a = *reinterpret_cast<const float4*>(rp);
+        const float2 e = *reinterpret_cast<const float2*>(rp + 4);
+        v[dy][0] = a.x; v[dy][1] = a.y; v[dy][2] = a.z; v[dy][3] = a.w; v[dy][4] = e.x; v[dy][5] = e.y;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wsm + ((chunk * KC + c) * 9 + tap) * 4);   // broadcast
+        const float wr[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+          const float wv = wr[o];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[o][q] = fmaf(wv, v[tap / 3][q + tap % 3], acc[o][q]);
+        }
+      }
+    }
+  }
+
+  const int oy = y0 + row, ox = x0 + col4;
+  if (oy < H && ox < W) {
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      float* dst = y + (size_t(b) * CO + o) * plane + size_t(oy) * W + ox;
+      float r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = relu ? fmaxf(acc[o][q], 0.f) : acc[o][q];
+      if (ox + 3 < W && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (ox + q < W) dst[q] = r[q];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace st {
+
+// true when one of the small-channel kernels takes the layer (then *rc is its launch status)
+bool conv3x3_small_fwd(const float* x, const float* w_packed, const float* bias, float* y, int n, int cin,
+                       int h, int w, int cout, int cout_pad, int pad_zero, int relu, hipStream_t s, int* rc) {
+  if (cin == 3 && cout <= ACO && cout % 16 == 0) {
+    const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 16);
+    const long long blocks = (long long)n * tiles_x * tiles_y;
+    if (blocks > 0x7fffffffLL) return false;
+    hipLaunchKernelGGL(conv3x3_cin_small_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, x, w_packed, bias, y,
+                       h, w, cout, cout_pad, pad_zero, relu, tiles_x, tiles_y);
+    *rc = check_launch("st_conv3x3_fwd(cin=3)");
+    return true;
+  }
+  if (cout == 3 && cin % KC == 0 && cin <= 512) {
+    const int tiles_x = cdiv(w, BTW), tiles_y = cdiv(h, BTH);
+    const long long blocks = (long long)n * tiles_x * tiles_y;
+    if (blocks > 0x7fffffffLL) return false;
+    hipLaunchKernelGGL(conv3x3_cout_small_kernel<3>, dim3((unsigned)blocks), dim3(256), size_t(cin) * 9 * 4 * sizeof(float),
+                       s, x, w_packed, bias, y,
+                       cin, h, w, cout_pad, pad_zero, relu, tiles_x, tiles_y);
+    *rc = check_launch("st_conv3x3_fwd(cout=3)");
+    return true;
+  }
+  return false;
+}
+
+}  // namespace st

@@ -121,5 +121,10 @@ def test_conv3x3_fused_ceil_pool(ops, compute, n, cin, cout, h, w):
     y2 = ops.maxpool2x2(ops.conv3x3(x.cuda(), wp, b.cuda(), cout, pad_mode="replicate", relu=True), True)
     torch.cuda.synchronize()
     assert y.shape == ref.shape
-    assert torch.equal(y, y2)                       # bit-identical to the unfused pair of launches
+    if cin == 3 and compute == "f32":
+        # the unfused fp32 launch of a 3-channel layer runs on the vector-ALU kernel (csrc/conv3x3_small.hip):
+        # same products, different summation order
+        assert rel_err(y, y2) < 1e-6
+    else:
+        assert torch.equal(y, y2)                   # bit-identical to the unfused pair of launches
     assert rel_err(y, ref) < (1e-5 if compute == "f32" else 1e-4)
