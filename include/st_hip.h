@@ -196,6 +196,14 @@ int st_adain_fwd(const float* content, const float* style, float* out,
                  float eps_content, float eps_style, float alpha,
                  float* stats, st_stream_t stream);
 
+/* Same, with the two eps values read from DEVICE memory (eps_dev[0] = eps_content, eps_dev[1] =
+ * eps_style): the trainable eps of transformer.py:11-12, 27-44 never has to be read back by the host, so
+ * a training / inference step has no host-device synchronisation in it (the reference's adjust_sigmoid
+ * reads the 1-element tensors on the host).  The caller guarantees 0 < eps < 1 (clamped by construction). */
+int st_adain_fwd_dev_eps(const float* content, const float* style, float* out,
+                         int n, int c, int hw_content, int hw_style,
+                         const float* eps_dev, float alpha, float* stats, st_stream_t stream);
+
 /* AdaIN backward.  gout: [n][c][hw_content] gradient of `out`; stats: as saved by st_adain_fwd.
  * dcontent / dstyle: nullable (the training loop needs neither: the encoder is frozen).
  * deps[2] = {d/d eps_content, d/d eps_style} (the trainable eps of transformer.py:11-12, before

@@ -8,9 +8,10 @@ from . import _lib, ops
 
 class _AdaINFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, content, style, eps_c_t, eps_s_t, alpha):
-        # eps_*_t: 1-element tensors (possibly with grad: sqrt(|param|) of adjust_sigmoid)
-        out, stats = ops.adain(content, style, float(eps_c_t), float(eps_s_t), alpha, save_stats=True)
+    def forward(ctx, content, style, eps2, alpha):
+        # eps2: 2-element device tensor (eps_content, eps_style), possibly with grad (sqrt(|param|) of
+        # adjust_sigmoid); it is read by the kernel, never by the host
+        out, stats = ops.adain(content, style, 0.0, 0.0, alpha, save_stats=True, eps_dev=eps2.detach().contiguous())
         ctx.alpha = alpha
         ctx.save_for_backward(content, style, stats)
         return out
@@ -32,9 +33,7 @@ class _AdaINFunction(torch.autograd.Function):
                                     _lib.dev_ptr(dstyle, "dstyle") if dstyle is not None else None,
                                     _lib.dev_ptr(deps, "deps"), _lib.dev_ptr(work, "workspace"),
                                     n, c, hc * wc, hs * ws, _lib.stream_ptr()), "st_adain_bwd")
-        d_eps_c = deps[0:1] if ctx.needs_input_grad[2] else None
-        d_eps_s = deps[1:2] if ctx.needs_input_grad[3] else None
-        return dcontent, dstyle, d_eps_c, d_eps_s, None
+        return dcontent, dstyle, (deps if ctx.needs_input_grad[2] else None), None
 
 
 def adain_autograd(content, style, content_eps, style_eps, alpha: float = 1.0):
@@ -47,4 +46,4 @@ def adain_autograd(content, style, content_eps, style_eps, alpha: float = 1.0):
             return e.reshape(1)
         return torch.tensor([float(e)], dtype=torch.float32, device=dev)
 
-    return _AdaINFunction.apply(content, style, as_t(content_eps), as_t(style_eps), float(alpha))
+    return _AdaINFunction.apply(content, style, torch.cat([as_t(content_eps), as_t(style_eps)]), float(alpha))

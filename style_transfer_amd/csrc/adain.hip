@@ -38,7 +38,9 @@ __global__ __launch_bounds__(NT) void adain_reg_kernel(const float* __restrict__
                                                       const float* __restrict__ style,
                                                       float* __restrict__ out, int hw_c, int hw_s,
                                                       float eps_c, float eps_s, float alpha,
-                                                      float* __restrict__ stats) {
+                                                      float* __restrict__ stats,
+    const float* __restrict__ eps_dev) {
+  if (eps_dev) { eps_c = eps_dev[0]; eps_s = eps_dev[1]; }   // device-resident eps (no host read)
   __shared__ float red[2 * NT / 64];
   const int tid = threadIdx.x;
   const size_t plane = blockIdx.x;
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(NTB) void adain_big_kernel(const float* __restrict_
                                                        const float* __restrict__ style,
                                                        float* __restrict__ out, int hw_c, int hw_s,
                                                        float eps_c, float eps_s, float alpha,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats,
+    const float* __restrict__ eps_dev) {
+  if (eps_dev) { eps_c = eps_dev[0]; eps_s = eps_dev[1]; }   // device-resident eps (no host read)
   constexpr int V4 = 32, NW = NTB / 64;
   __shared__ float red[NW];
   __shared__ double redd[2 * NW];
@@ -273,7 +277,9 @@ __global__ __launch_bounds__(NT) void adain_stream_kernel(const float* __restric
                                                          const float* __restrict__ style,
                                                          float* __restrict__ out, int hw_c,
                                                          int hw_s, float eps_c, float eps_s,
-                                                         float alpha, float* __restrict__ stats) {
+                                                         float alpha, float* __restrict__ stats,
+    const float* __restrict__ eps_dev) {
+  if (eps_dev) { eps_c = eps_dev[0]; eps_s = eps_dev[1]; }   // device-resident eps (no host read)
   __shared__ float red[NT / 64];
   const size_t plane = blockIdx.x;
   const float* cp = content + plane * hw_c;
@@ -384,14 +390,14 @@ extern "C" int st_adain_bwd(const float* gout, const float* content, const float
   return st::check_launch("st_adain_bwd");
 }
 
-extern "C" int st_adain_fwd(const float* content, const float* style, float* out, int n, int c,
-                            int hw_content, int hw_style, float eps_content, float eps_style,
-                            float alpha, float* stats, st_stream_t stream) {
+static int adain_fwd_impl(const float* content, const float* style, float* out, int n, int c,
+                          int hw_content, int hw_style, float eps_content, float eps_style,
+                          const float* eps_dev, float alpha, float* stats, st_stream_t stream) {
   ST_REQUIRE(content && style && out, "st_adain_fwd: null pointer");
   ST_REQUIRE(n > 0 && c > 0 && hw_content > 0 && hw_style > 0,
              "st_adain_fwd: bad dims n=%d c=%d hw_c=%d hw_s=%d", n, c, hw_content, hw_style);
   // transformer.py:19 `assert 0 < eps < 1.0`
-  ST_REQUIRE(eps_content > 0.f && eps_content < 1.f && eps_style > 0.f && eps_style < 1.f,
+  ST_REQUIRE(eps_dev || (eps_content > 0.f && eps_content < 1.f && eps_style > 0.f && eps_style < 1.f),
              "st_adain_fwd: eps must be in (0,1): %g %g", eps_content, eps_style);
   const long long planes = (long long)n * c;
   ST_REQUIRE(planes <= 0x7fffffffLL, "st_adain_fwd: too many planes");
@@ -405,18 +411,32 @@ extern "C" int st_adain_fwd(const float* content, const float* style, float* out
   const int need = std::max(hw_content, hw_style);
   if (vec_ok && need <= NT * 4 * 4) {
     hipLaunchKernelGGL(adain_reg_kernel<4>, grid, block, 0, s, content, style, out, hw_content,
-                       hw_style, eps_content, eps_style, alpha, stats);
+                       hw_style, eps_content, eps_style, alpha, stats, eps_dev);
   } else if (vec_ok && need <= NT * 4 * 16) {
     hipLaunchKernelGGL(adain_reg_kernel<16>, grid, block, 0, s, content, style, out, hw_content,
-                       hw_style, eps_content, eps_style, alpha, stats);
+                       hw_style, eps_content, eps_style, alpha, stats, eps_dev);
   } else if (vec_ok && hw_content <= NTB * 4 * 32 && hw_style >= 2) {
     hipLaunchKernelGGL(adain_big_kernel, grid, dim3(NTB), 0, s, content, style, out, hw_content,
-                       hw_style, eps_content, eps_style, alpha, stats);
+                       hw_style, eps_content, eps_style, alpha, stats, eps_dev);
   } else {
     hipLaunchKernelGGL(adain_stream_kernel, grid, block, 0, s, content, style, out, hw_content,
-                       hw_style, eps_content, eps_style, alpha, stats);
+                       hw_style, eps_content, eps_style, alpha, stats, eps_dev);
   }
   return st::check_launch("st_adain_fwd");
+}
+
+extern "C" int st_adain_fwd(const float* content, const float* style, float* out, int n, int c,
+                            int hw_content, int hw_style, float eps_content, float eps_style,
+                            float alpha, float* stats, st_stream_t stream) {
+  return adain_fwd_impl(content, style, out, n, c, hw_content, hw_style, eps_content, eps_style, nullptr, alpha,
+                        stats, stream);
+}
+
+extern "C" int st_adain_fwd_dev_eps(const float* content, const float* style, float* out, int n, int c,
+                                    int hw_content, int hw_style, const float* eps_dev, float alpha,
+                                    float* stats, st_stream_t stream) {
+  ST_REQUIRE(eps_dev, "st_adain_fwd_dev_eps: null eps pointer");
+  return adain_fwd_impl(content, style, out, n, c, hw_content, hw_style, 0.f, 0.f, eps_dev, alpha, stats, stream);
 }
 
 extern "C" int st_meanstd_fwd(const float* x, float* mean, float* stdv, int planes, int hw,

@@ -287,8 +287,11 @@ def maxpool2x2(x: torch.Tensor, ceil_mode: bool) -> torch.Tensor:
 
 
 def adain(content: torch.Tensor, style: torch.Tensor, eps_content: float, eps_style: float,
-          alpha: float = 1.0, save_stats: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """alpha * AdaIN(content, style) + (1 - alpha) * content (transformer.py:46-54, trainer.py:702)."""
+          alpha: float = 1.0, save_stats: bool = False,
+          eps_dev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """alpha * AdaIN(content, style) + (1 - alpha) * content (transformer.py:46-54, trainer.py:702).
+    ``eps_dev``: optional 2-element device tensor (eps_content, eps_style) read by the kernel instead of the
+    two host floats -- no host read of the trainable eps, no synchronisation."""
     lib = _lib.load()
     assert content.dim() == 4 and style.dim() == 4
     assert content.shape[:2] == style.shape[:2]          # transformer.py:47
@@ -299,11 +302,19 @@ def adain(content: torch.Tensor, style: torch.Tensor, eps_content: float, eps_st
     ev = None
     if KERNEL_TIMER.enabled:   # algorithmic bytes: read content once, read style once, write out once
         ev = KERNEL_TIMER.record("adain_fwd", 0.0, 4.0 * (2 * content.numel() + style.numel()))
-    _lib.check(lib.st_adain_fwd(_lib.dev_ptr(content, "content"), _lib.dev_ptr(style, "style"),
-                                _lib.dev_ptr(out, "out"), n, c, hc * wc, hs * ws, float(eps_content),
-                                float(eps_style), float(alpha),
-                                _lib.dev_ptr(stats, "stats") if stats is not None else None,
-                                _lib.stream_ptr()), "st_adain_fwd")
+    if eps_dev is not None:
+        assert eps_dev.numel() == 2, "eps_dev holds (eps_content, eps_style)"
+        _lib.check(lib.st_adain_fwd_dev_eps(_lib.dev_ptr(content, "content"), _lib.dev_ptr(style, "style"),
+                                            _lib.dev_ptr(out, "out"), n, c, hc * wc, hs * ws,
+                                            _lib.dev_ptr(eps_dev, "eps_dev"), float(alpha),
+                                            _lib.dev_ptr(stats, "stats") if stats is not None else None,
+                                            _lib.stream_ptr()), "st_adain_fwd_dev_eps")
+    else:
+        _lib.check(lib.st_adain_fwd(_lib.dev_ptr(content, "content"), _lib.dev_ptr(style, "style"),
+                                    _lib.dev_ptr(out, "out"), n, c, hc * wc, hs * ws, float(eps_content),
+                                    float(eps_style), float(alpha),
+                                    _lib.dev_ptr(stats, "stats") if stats is not None else None,
+                                    _lib.stream_ptr()), "st_adain_fwd")
     if ev is not None:
         ev.record()
     return out, stats

@@ -37,6 +37,13 @@ class AdaIN(nn.Module):
             scaled_output = x
         return scaled_output
 
+    @staticmethod
+    def adjust_sigmoid_device(x, upper_limit=0.3):
+        """adjust_sigmoid without the host read: sqrt(|x|).clamp(1e-5, upper_limit) stays a 1-element device
+        tensor.  Same value as transformer.py:27-36 in all three branches; where the reference returns a Python
+        float (clamped, no gradient) the clamp passes a ZERO gradient to the parameter instead of none."""
+        return torch.pow(torch.abs(x), 0.5).clamp(1e-5, upper_limit)
+
     def get_current_eps(self):
         """transformer.py:38-44."""
         if torch.cuda.is_available():
@@ -53,14 +60,19 @@ class AdaIN(nn.Module):
                 isinstance(e, torch.Tensor) and _needs_grad(e) for e in (style_eps, content_eps)):
             from .autograd_adain import adain_autograd
             return adain_autograd(content_feat, style_feat, content_eps, style_eps, alpha)
+        if isinstance(content_eps, torch.Tensor) and isinstance(style_eps, torch.Tensor) and content_eps.is_cuda:
+            eps2 = torch.cat([content_eps.detach().reshape(1), style_eps.detach().reshape(1)])
+            out, _ = ops.adain(content_feat, style_feat, 0.0, 0.0, alpha, eps_dev=eps2)
+            return out
         out, _ = ops.adain(content_feat, style_feat, float(content_eps), float(style_eps), alpha)
         return out
 
     def forward(self, content_feat, style_feat, alpha: float = 1.0):
         """transformer.py:56-59.  ``alpha`` (default 1.0 = reference behaviour) fuses
-        ``alpha * t + (1 - alpha) * content_feat`` into the same kernel."""
+        ``alpha * t + (1 - alpha) * content_feat`` into the same kernel.  The two eps stay on the device
+        (adjust_sigmoid_device): no host synchronisation inside a step."""
         return self.adaptive_instance_normalization(
             content_feat, style_feat,
-            style_eps=self.adjust_sigmoid(self.style_eps, self.eps_limit),
-            content_eps=self.adjust_sigmoid(self.content_eps, self.eps_limit),
+            style_eps=self.adjust_sigmoid_device(self.style_eps, self.eps_limit),
+            content_eps=self.adjust_sigmoid_device(self.content_eps, self.eps_limit),
             alpha=alpha)
