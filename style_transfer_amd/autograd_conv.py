@@ -70,11 +70,11 @@ class DecoderChainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cache, specs, *params):
         acts = [x]
-        compute = None
+        compute = []        # per layer: the backward of a layer uses its forward's precision
         for i, (key, cout, up, relu) in enumerate(specs):
             w, b = params[2 * i], params[2 * i + 1]
             wp = cache.get(key, w, False)
-            compute = ops.conv_family(wp, int(w.shape[0]), int(w.shape[1]))
+            compute.append(ops.conv_family(wp, int(w.shape[0]), int(w.shape[1])))
             acts.append(ops.conv3x3(acts[-1], wp, b.detach(), cout, up, ops.PAD_REPLICATE, relu))
         ctx.cache, ctx.specs, ctx.compute = cache, specs, compute
         ctx.save_for_backward(*acts[:-1], *params)          # layer inputs (the last output is not needed)
@@ -97,11 +97,11 @@ class DecoderChainFunction(torch.autograd.Function):
             # reference's last decoder conv has no ReLU (generator.py:117), which is asserted in Decoder
             if ctx.needs_input_grad[3 + 2 * i] or ctx.needs_input_grad[4 + 2 * i]:
                 dw, db = ops.conv3x3_wgrad(x_i, g, None, want_bias=True, upsample2x=up,
-                                           pad_mode=ops.PAD_REPLICATE, compute=ctx.compute)
+                                           pad_mode=ops.PAD_REPLICATE, compute=ctx.compute[i])
                 grads[2 * i] = dw if ctx.needs_input_grad[3 + 2 * i] else None
                 grads[2 * i + 1] = db if ctx.needs_input_grad[4 + 2 * i] else None
             if i > 0 or ctx.needs_input_grad[0]:
-                wpt = ctx.cache.get(key, w, True, ctx.compute)
+                wpt = ctx.cache.get(key, w, True, ctx.compute[i])
                 gate = x_i if (i > 0 and ctx.specs[i - 1][3]) else None     # input is a ReLU output
                 g = ops.conv3x3_dgrad(g, None, wpt, int(w.shape[1]), up, ops.PAD_REPLICATE, dx_gate=gate)
                 if i == 0:

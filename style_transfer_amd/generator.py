@@ -39,11 +39,13 @@ class _PackedWeightCache:
     def __init__(self):
         self._c: Dict[Tuple[int, bool], Tuple[int, int, torch.Tensor]] = {}
 
-    def get(self, key, w: torch.Tensor, transpose_flip: bool = False, compute: Optional[str] = None) -> torch.Tensor:
+    def get(self, key, w: torch.Tensor, transpose_flip: bool = False, compute: Optional[str] = None,
+            forward_only: bool = False) -> torch.Tensor:
         compute = compute or precision.get_compute_dtype()
-        if compute == "bf16x3" and 3 in (int(w.shape[0]), int(w.shape[1])):
+        if compute == "bf16x3" and forward_only and 3 in (int(w.shape[0]), int(w.shape[1])):
             # the 3-channel layers are HBM-bound: the exact-fp32 vector-ALU kernels (csrc/conv3x3_small.hip)
-            # are as fast as any matrix-pipe form, so the fp32-grade mode keeps them exact
+            # are as fast as any matrix-pipe form, so the fp32-grade mode keeps them exact (forward-only callers:
+            # a layer that will be differentiated stays on the split kernels so that its backward does too)
             compute = "f32"
         ent = self._c.get((key, transpose_flip, compute))
         if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
