@@ -366,9 +366,10 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
     }
 
 
-def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: int = None, side: int = None):
+def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: int = None, side: int = None,
+              hip_graph: bool = False):
     from oracle import ref_ops as R     # seeded synthetic weights only
-    from style_transfer_amd.trainer import GradBucket, Trainer
+    from style_transfer_amd.trainer import GradBucket, GraphedStep, Trainer
 
     dev = ctx.dev
     import contextlib
@@ -379,13 +380,16 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
                      delta=10.0, eps=0.1, do_decoder_train=True, optim_name={"optim_name": "adam"},
                      use_VincentStyleLoss=use_vincent, content_layers_idx=CONTENT_IDX, style_layers_idx=STYLE_IDX,
                      encoder_weights=R.make_encoder_state(0), vgg_weights=R.make_loss_vgg_state(2, upto=max(STYLE_IDX)),
-                     device=dev)
+                     device=dev, use_hip_graph=hip_graph)
         encoder, decoder, transformer, loss_vgg = tr.build_model()
         decoder.load_state_dict(R.make_decoder_state(1))
         params = tr.trainable_parameters(transformer, decoder)
-        opt = tr.get_optimizer("adam", params, 1e-4, {"optim_name": "adam"})
+        hip_graph = hip_graph and tr.graph_capable()
+        lr = torch.tensor(1e-4, device=dev) if hip_graph else 1e-4
+        opt = tr.get_optimizer("adam", params, lr, tr.graph_optim_kwargs())
         step = tr.make_step(encoder, decoder, transformer, loss_vgg)
     bucket = GradBucket(params)
+    graphed = GraphedStep(tr, step, opt, bucket) if hip_graph else None
     g = torch.Generator().manual_seed(4321 + ctx.rank)
     s = side or args.train_side
     tb = batch or args.train_batch
@@ -393,11 +397,17 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
     style = torch.rand(tb, 3, s, s, generator=g).to(dev)
 
     def one():
+        if graphed is not None:
+            return graphed(content, style)      # 3 eager warm-up calls, capture, then replays (all before the timed loop)
         return tr.optimize_step(step, opt, bucket, content, style)
 
     from style_transfer_amd import precision
     steps, warmup = args.train_steps, args.train_warmup
     with precision.compute_dtype(compute):
+        if graphed is not None:
+            for _ in range(GraphedStep.WARMUP + 1):     # eager warm-up calls + the capture: never inside the timed loop
+                one()
+            assert graphed.graph is not None
         elapsed, _, losses, _ = timed(ctx, one, steps, warmup, collect_kernels=False)
     total = float(losses[4].detach())
     assert total == total, "training loss is NaN"
@@ -407,6 +417,7 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "scaling": "weak",
             "dtype": compute, "style_loss": "VincentStyleLoss (covariance MFMA + eigh)" if use_vincent
             else "AdaINStyleLoss (mean/std)",
+            "launch": "one HIP graph replay per step (GraphedStep)" if graphed is not None else "eager launches",
             "config": {"workload": ("BASELINE configs[2]: " if (compute, tb, s) == ("f32", 8, 256) else "") +
                                    f"training step batch {tb} at {s}x{s} {compute} per "
                                    "GPU: 2x encoder, AdaIN, decoder, Normalize, loss VGG19 (idx 21 / 2,7,14,19,25), "
@@ -432,6 +443,7 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--no-gram", action="store_true", help="skip the VincentStyleLoss variant of the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hip-graph", action="store_true", help="skip the HIP-graph-replay variants of the train legs")
     ap.add_argument("--compute", choices=["f32", "bf16", "bf16x3"], default="f32",
                     help="conv compute precision of the main legs (profiling aid; the headline legs are f32)")
     ap.add_argument("--no-bf16", action="store_true",
@@ -447,6 +459,10 @@ def main():
         line = run_inference(ctx, args, compute=args.compute)
     if args.mode in ("both", "train"):
         train = run_train(ctx, args, use_vincent=False, compute=args.compute)
+        if ctx.world == 1 and not args.no_hip_graph:
+            # the same step replayed from a HIP graph (single process; the N > 1 legs stay eager)
+            g = run_train(ctx, args, use_vincent=False, compute=args.compute, hip_graph=True)
+            train["hip_graph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "launch")}
         if not args.no_gram:
             train["gram"] = run_train(ctx, args, use_vincent=True, compute=args.compute)
         if args.mode == "train":
@@ -469,7 +485,8 @@ def main():
         if args.mode in ("both", "infer"):
             x3["inference"] = run_inference(ctx, args, compute="bf16x3")
         if args.mode in ("both", "train"):
-            x3["train"] = run_train(ctx, args, use_vincent=False, compute="bf16x3")
+            x3["train"] = run_train(ctx, args, use_vincent=False, compute="bf16x3",
+                                    hip_graph=(ctx.world == 1 and not args.no_hip_graph))
         line["bf16x3"] = x3
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline:

@@ -4,7 +4,7 @@
     python -m torch.distributed.run --nproc-per-node N -m style_transfer_amd.train ...      (data parallel)
 
 Same flags and defaults as the reference; additions: ``--encoder_weights``, ``--decoder_weights``,
-``--vgg_weights`` (the blobs the reference hard-codes or downloads), ``--dtype f32|bf16``.
+``--vgg_weights`` (the blobs the reference hard-codes or downloads), ``--dtype f32|bf16|bf16x3``, ``--hip_graph``.
 Under ``torch.distributed.run`` one process drives each GPU (RCCL), the sampler is sharded by rank and
 rank 0 writes the checkpoints.
 """
@@ -83,6 +83,8 @@ def parse_args(args):
     parser.add_argument('--decoder_weights', type=str, default=None, help="feature_invertor_conv4_1.pth")
     parser.add_argument('--vgg_weights', type=str, default=None, help="torchvision vgg19 state dict (vgg19-dcbb9e9d.pth)")
     parser.add_argument('--dtype', choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")
+    parser.add_argument('--hip_graph', action='store_true',
+                        help="capture the training step in a HIP graph and replay it (single process)")
     args = parser.parse_args(args)
 
     # Sanity check (train.py:89-99)
@@ -149,7 +151,7 @@ def main(args):
         use_pretrained_WCTDECODER=args.use_pretrained_WCTDECODER,
         grayscale_content_transform=args.grayscale_content_transform, use_VincentStyleLoss=args.use_VincentStyleLoss,
         config=args, encoder_weights=args.encoder_weights, decoder_weights=args.decoder_weights,
-        vgg_weights=args.vgg_weights, compute_dtype=args.dtype)
+        vgg_weights=args.vgg_weights, compute_dtype=args.dtype, use_hip_graph=args.hip_graph)
     history = trainer.train()
     if world > 1:
         import torch.distributed as dist

@@ -158,11 +158,76 @@ class StyleTransferStep:
 
 
 # ---------------------------------------------------------------------------------------------
+class GraphedStep:
+    """One training step captured in a HIP graph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replayed.
+
+    A step is ~400 kernel launches through ctypes plus the autograd tape; at small shapes (or on a busy host)
+    the GPU waits for the host.  Every launch of the step goes to torch's current stream, the step has no
+    host read in it (AdaIN's eps stays on the device), workspaces come from torch's allocator -- so the whole
+    optimize_step (forward, losses, backward, optimizer) records into one graph; a replay costs ~0.1 ms of
+    host time.  Inputs are copied into static buffers; the returned losses are static tensors overwritten by
+    every replay.  Needs an optimizer built with ``capturable=True`` (Trainer does that when
+    ``use_hip_graph`` is set) and a fixed batch shape: other shapes run eagerly.  Single-process only for
+    now: with world_size > 1 the step runs eagerly (the all-reduce is not captured)."""
+
+    WARMUP = 3
+
+    def __init__(self, trainer: "Trainer", step: StyleTransferStep, optimizer, bucket: GradBucket):
+        self.trainer, self.step, self.optimizer, self.bucket = trainer, step, optimizer, bucket
+        self.graph = None
+        self.shape = None
+        self.static_content = self.static_style = None
+        self.losses = None
+        self.eager_calls = 0
+        self._side = None
+
+    def _eager(self, content, style):
+        return self.trainer.optimize_step(self.step, self.optimizer, self.bucket, content, style)
+
+    def __call__(self, content: torch.Tensor, style: torch.Tensor):
+        key = (tuple(content.shape), tuple(style.shape))
+        if self.trainer.world_size > 1 or (self.shape is not None and key != self.shape):
+            return self._eager(content, style)            # ragged last batch / data parallel: eager
+        if self.graph is None:
+            if self.eager_calls < self.WARMUP:             # allocator, packed-weight caches, optimizer state
+                # Warm-up steps run on a side stream (the PyTorch capture recipe): autograd's AccumulateGrad
+                # nodes remember the stream they were created on, and nodes tied to the legacy default stream
+                # make the backward inside the capture synchronise with it, which breaks the capture.
+                self.eager_calls += 1
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                cur = torch.cuda.current_stream()
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    out = self._eager(content, style)
+                cur.wait_stream(self._side)
+                for t in (content, style, *out):
+                    t.record_stream(self._side)
+                return out
+            self.shape = key
+            self.static_content, self.static_style = content.clone(), style.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # side-stream warm-up: intended
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                self.losses = self._eager(self.static_content, self.static_style)
+            self.graph = graph
+            # the capture recorded the step without running it: the replay below IS this call's step
+        else:
+            self.static_content.copy_(content, non_blocking=True)
+            self.static_style.copy_(style, non_blocking=True)
+        self.graph.replay()
+        return self.losses
+
+
 class Trainer:
     """Constructor keywords, optimizer names, checkpoint layout and resume rules of the reference
     Trainer (trainer.py:39-108, 201-232, 304-388, 607-655).  Extra keywords (all optional):
     ``encoder_weights`` / ``decoder_weights`` / ``vgg_weights`` (paths or state dicts; the blobs
-    the reference hard-codes are not shipped), ``device``, ``compute_dtype`` ("f32" | "bf16")."""
+    the reference hard-codes are not shipped), ``device``, ``compute_dtype`` ("f32" | "bf16" | "bf16x3"),
+    ``use_hip_graph`` (capture the training step in a HIP graph and replay it, GraphedStep)."""
 
     def __init__(self, dataloaders, output_dir: str, num_train_epochs: int, per_device_batch_size: int,
                  learning_rate: float, alpha: float, beta: float, gamma: float, seed: int = 42,
@@ -175,7 +240,7 @@ class Trainer:
                  grayscale_content_transform: bool = False, use_VincentStyleLoss: bool = False,
                  content_layers_idx: List[int] = [12, 16, 21], style_layers_idx: List[int] = [0, 5, 10, 19, 28],
                  encoder_weights=None, decoder_weights=None, vgg_weights=None, device=None,
-                 compute_dtype: str = "f32"):
+                 compute_dtype: str = "f32", use_hip_graph: bool = False):
         self.output_dir = output_dir
         self.dataloaders = dataloaders.__call__() if callable(dataloaders) else dataloaders
         self.per_device_batch_size = per_device_batch_size
@@ -203,7 +268,8 @@ class Trainer:
         self.device = torch.device(device) if device is not None else \
             torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.encoder_weights, self.decoder_weights, self.vgg_weights = encoder_weights, decoder_weights, vgg_weights
-        self.compute_dtype = compute_dtype       # "f32" | "bf16" (precision.py)
+        self.compute_dtype = compute_dtype       # "f32" | "bf16" | "bf16x3" (precision.py)
+        self.use_hip_graph = bool(use_hip_graph)  # replay the step from a HIP graph (GraphedStep)
         if self.with_tracking:
             raise RuntimeError("wandb tracking is outside the hot path this build covers (SURVEY.md section 2)")
         self.wandb = None
@@ -232,6 +298,21 @@ class Trainer:
             return table[optimizer_name](parameters, lr=learning_rate, **kwargs_clone)
         except TypeError:
             raise TypeError("Invalid argument for optimizer!")
+
+    _CAPTURABLE = ('adam', 'adamw', 'adamax', 'adagrad', 'adadelta', 'rmsprop', 'rprop')
+
+    def graph_capable(self) -> bool:
+        """HIP-graph replay of the step: asked for, single process, a capturable torch optimizer and no
+        rocSOLVER eigendecomposition (VincentStyleLoss) in the step."""
+        return (self.use_hip_graph and self.world_size == 1 and not self.use_VincentStyleLoss
+                and self.device.type == 'cuda' and self.optim_name['optim_name'].lower() in self._CAPTURABLE)
+
+    def graph_optim_kwargs(self) -> dict:
+        """Optimizer kwargs for graph replay: ``capturable=True`` (optimizer state and step count on the device)."""
+        kw = dict(self.optim_name)
+        if self.graph_capable():
+            kw['capturable'] = True
+        return kw
 
     def build_model(self):
         """trainer.py:234-244 (one loss network serves both index lists)."""
@@ -375,8 +456,11 @@ class Trainer:
         precision.set_compute_dtype(self.compute_dtype)
         encoder, decoder, transformer, loss_vgg = self.build_model()
         params = self.trainable_parameters(transformer, decoder)
-        transformer_optimizer = self.get_optimizer(self.optim_name['optim_name'], params, self.learning_rate,
-                                                   self.optim_name)
+        # graph replay: the learning rate lives in a device tensor so that the scheduler's updates (lr.fill_)
+        # reach the captured optimizer kernels
+        lr = torch.tensor(float(self.learning_rate), device=self.device) if self.graph_capable() else self.learning_rate
+        transformer_optimizer = self.get_optimizer(self.optim_name['optim_name'], params, lr,
+                                                   self.graph_optim_kwargs())
         transformer_optimizer, init_epoch, loss_list, completed_step, last_session_epoch = \
             self.resume(transformer, decoder, transformer_optimizer)
         train_loader = self.dataloaders['train']
@@ -388,6 +472,8 @@ class Trainer:
         scheduler_count = 0
         step_engine = self.make_step(encoder, decoder, transformer, loss_vgg)
         bucket = GradBucket(params)
+        run_step = GraphedStep(self, step_engine, transformer_optimizer, bucket) if self.graph_capable() else \
+            (lambda c, s: self.optimize_step(step_engine, transformer_optimizer, bucket, c, s))
         history = []
         for epoch in range(init_epoch, self.num_train_epochs):
             sums = torch.zeros(5, dtype=torch.float64, device=self.device)
@@ -397,7 +483,7 @@ class Trainer:
             for step, batch in enumerate(train_loader):
                 content_imgs = batch['content_image'].to(self.device, non_blocking=True).contiguous()
                 style_imgs = batch['style_image'].to(self.device, non_blocking=True).contiguous()
-                losses = self.optimize_step(step_engine, transformer_optimizer, bucket, content_imgs, style_imgs)
+                losses = run_step(content_imgs, style_imgs)
                 completed_step += step                                          # trainer.py:475 (sic: index, not 1)
                 sums += torch.stack([l.detach().double().reshape(()) for l in losses])
                 scheduler_count += 1

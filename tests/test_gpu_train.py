@@ -118,3 +118,55 @@ def test_trainer_loop_and_checkpoint(tmp_path):
         kw2 = dict(kw, num_train_epochs=3, resume_from_checkpoint=str(last), output_dir=str(tmp_path / "resumed"))
         hist2 = Trainer({"train": batches}, **kw2).train()
     assert [h["epoch"] for h in hist2] == [2]
+
+
+def _trainer_for_steps(use_graph):
+    import warnings
+    from style_transfer_amd.trainer import GradBucket, GraphedStep, Trainer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = Trainer({"train": []}, output_dir="/tmp/st_graph_test", num_train_epochs=1, per_device_batch_size=2,
+                     learning_rate=1e-3, alpha=1.0, beta=10.0, gamma=1.0, delta=10.0, eps=0.1, do_decoder_train=True,
+                     optim_name={"optim_name": "adam"}, content_layers_idx=[21], style_layers_idx=[2, 7, 14, 19, 25],
+                     encoder_weights=R.make_encoder_state(0), vgg_weights=R.make_loss_vgg_state(2, upto=25),
+                     device="cuda", use_hip_graph=True)
+        assert tr.graph_capable()
+        encoder, decoder, transformer, loss_vgg = tr.build_model()
+        decoder.load_state_dict(R.make_decoder_state(1))
+        params = tr.trainable_parameters(transformer, decoder)
+        lr = torch.tensor(1e-3, device="cuda")
+        opt = tr.get_optimizer("adam", params, lr, tr.graph_optim_kwargs())     # capturable Adam in both runs
+        step = tr.make_step(encoder, decoder, transformer, loss_vgg)
+    bucket = GradBucket(params)
+    run = GraphedStep(tr, step, opt, bucket) if use_graph else \
+        (lambda c, s: tr.optimize_step(step, opt, bucket, c, s))
+    return run, decoder, transformer, lr
+
+
+def test_hip_graph_replay_matches_eager_steps():
+    """GraphedStep (3 eager warm-up steps, capture, replays) walks the same trajectory as eager steps: same losses
+    and same decoder weights after 8 optimizer steps on changing batches, including a learning-rate change that
+    has to reach the captured optimizer through the device-resident lr tensor, and a ragged batch run eagerly."""
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.rand(2, 3, 64, 64, generator=g).cuda(), torch.rand(2, 3, 64, 64, generator=g).cuda())
+               for _ in range(8)]
+    batches.insert(6, (torch.rand(1, 3, 64, 64, generator=g).cuda(), torch.rand(1, 3, 64, 64, generator=g).cuda()))
+    results = []
+    for use_graph in (False, True):
+        run, decoder, transformer, lr = _trainer_for_steps(use_graph)
+        totals = []
+        for i, (c, s) in enumerate(batches):
+            if i == 5:
+                lr.fill_(3e-4)
+            losses = run(c, s)
+            totals.append(float(losses[4].detach()))
+        if use_graph:
+            assert run.graph is not None and run.shape == ((2, 3, 64, 64), (2, 3, 64, 64))
+        torch.cuda.synchronize()
+        results.append((totals, [p.detach().clone() for p in decoder.parameters()],
+                        [p.detach().clone() for p in transformer.parameters()]))
+    (t0, d0, a0), (t1, d1, a1) = results
+    for a, b in zip(t0, t1):
+        assert abs(a - b) <= 1e-5 * abs(a), (t0, t1)
+    for a, b in zip(d0 + a0, d1 + a1):
+        assert rel_l2(b, a) < 1e-5
