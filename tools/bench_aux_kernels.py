@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Timing of the non-conv kernels of the training step against their rooflines:
+RGB-uv histogram block, TV loss, mean/std statistics, MSE, Normalize (HBM bytes) and the covariance
+("Gram") kernel (MFMA FLOPs), forward and backward through the module API, back-to-back launches
+between one event pair.  Prints one line per case."""
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from style_transfer_amd import ops  # noqa: E402
+from style_transfer_amd.losses import AdaINContentLoss, AdaINStyleLoss, HistLoss, TVLoss, VincentStyleLoss  # noqa: E402
+
+HBM, FP32_MFMA = 8000.0, 157.3
+
+
+def timeit(fn, iters=20):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3      # us
+
+
+def line(name, us, nbytes=None, flops=None):
+    s = f"{name:58s} {us:9.1f} us"
+    if nbytes:
+        gbs = nbytes / us / 1e3
+        s += f"  {nbytes / 1e6:8.2f} MB  {gbs:7.0f} GB/s  {100 * gbs / HBM:5.1f}% of HBM peak"
+    if flops:
+        tf = flops / us / 1e6
+        s += f"  {flops / 1e9:8.2f} GF  {tf:6.1f} TF/s  {100 * tf / FP32_MFMA:5.1f}% of fp32 MFMA peak"
+    print(s, flush=True)
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hist, tv, sty, mse, vin = HistLoss(), TVLoss(), AdaINStyleLoss(), AdaINContentLoss(), VincentStyleLoss()
+    for b, s in ((8, 256), (8, 512), (16, 2048)):
+        x = torch.rand(b, 3, s, s, device=dev, generator=g)
+        with torch.no_grad():
+            us = timeit(lambda: hist.histogram_block(x))
+        line(f"rgbuv_hist fwd  B={b} S={s}", us, nbytes=4.0 * (x.numel() + b * 3 * 64 * 64))
+        xg = x.clone().requires_grad_(True)
+        t = torch.rand(b, 3, 64, 64, device=dev, generator=g)
+
+        def fb():
+            xg.grad = None
+            (hist.histogram_block(xg) * t).sum().backward()
+        line(f"rgbuv_hist fwd+bwd  B={b} S={s}", timeit(fb), nbytes=4.0 * (3 * x.numel()))
+        with torch.no_grad():
+            line(f"tv fwd  B={b} S={s}", timeit(lambda: tv(x)), nbytes=4.0 * x.numel())
+            line(f"normalize fwd  B={b} S={s}", timeit(lambda: ops.normalize(x, [.485, .456, .406], [.229, .224, .225])),
+                 nbytes=8.0 * x.numel())
+    for b, c, hw in ((8, 64, 256), (8, 128, 128), (8, 256, 64), (8, 512, 32), (16, 512, 64)):
+        f = torch.randn(b, c, hw, hw, device=dev, generator=g)
+        f2 = torch.randn(b, c, hw, hw, device=dev, generator=g)
+        with torch.no_grad():
+            line(f"mean_std  [{b},{c},{hw},{hw}]", timeit(lambda: ops.mean_std(f)), nbytes=4.0 * f.numel())
+            line(f"mse fwd  [{b},{c},{hw},{hw}]", timeit(lambda: mse(f, f2)), nbytes=8.0 * f.numel())
+            line(f"covariance (Gram) fwd  [{b},{c},{hw},{hw}]", timeit(lambda: vin.calc_2_moments(f)),
+                 flops=2.0 * b * c * c * hw * hw)
+        fg = f.clone().requires_grad_(True)
+
+        def sb():
+            fg.grad = None
+            sty(fg, f2).backward()
+        line(f"mean/std style loss fwd+bwd  [{b},{c},{hw},{hw}]", timeit(sb), nbytes=4.0 * 4 * f.numel())
+
+
+if __name__ == "__main__":
+    main()
