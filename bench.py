@@ -56,7 +56,7 @@ DOMINANT_BF16X3 = "conv3x3_bf16x3_kernel<1,4,2,4>"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 # HBM bytes per launch of the dominant kernel from profiles/r1_bench_infer_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
 # KiB, averaged over its 20 launches per inference step; 4-B-per-lane loads: FETCH_SIZE taken as reported)
-DOMINANT_TRAFFIC_BYTES = (833426.1 + 298188.8) * 1024
+DOMINANT_TRAFFIC_BYTES = (529644.5 + 239206.4) * 1024
 
 
 def encoder_decoder_flops(side: int):
