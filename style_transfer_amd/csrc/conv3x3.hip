@@ -62,8 +62,12 @@ struct Cfg {
   static constexpr size_t LDS_BYTES = size_t(W_ELEMS + X_ELEMS) * sizeof(float);
 };
 
-template <int MT, int NT, int WM, int WP, bool GATE>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_f32_kernel(ConvParams p) {
+// OCC = waves per SIMD the register allocation aims at (= blocks per CU: a block has one wave per SIMD).
+// The block is single-buffered in LDS (MFMA phase, barrier, LDS-store phase, barrier), so it is the OTHER blocks
+// on the CU that keep the matrix pipe busy during a block's staging phase: at 3 blocks per CU (<= 168 registers,
+// 3 x 43 KB of LDS) the large layers run at 135-137 TFLOP/s instead of 121-126 at 2 (220 registers).
+template <int MT, int NT, int WM, int WP, bool GATE, int OCC>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv3x3_f32_kernel(ConvParams p) {
   using C = Cfg<MT, NT, WM, WP>;
   static_assert(WM * WP == 4, "four waves per block");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -320,7 +324,18 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3: too many tiles (%lld)", ptiles * p.ctiles);
   p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
   dim3 grid((unsigned)(ptiles * p.ctiles));
-  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP, GATE>), grid, dim3(NTHREADS),
+  // 3 blocks per CU unless the grid is between one and two rounds of 768 slots (then the second, mostly empty
+  // round costs more than the third block gains: 512->256 at 64x64, batch 16: 110 vs 124 TFLOP/s); the gated
+  // (data-gradient) form and the 32-channel tile need > 168 registers and stay at 2.
+  const long long blocks = ptiles * p.ctiles;
+  const bool occ3 = !GATE && MT == 2 && !(blocks > 768 && blocks < 1536);
+  if constexpr (!GATE && MT == 2) {
+    if (occ3) {
+      hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP, GATE, 3>), grid, dim3(NTHREADS), C::LDS_BYTES, stream, p);
+      return st::check_launch("st_conv3x3");
+    }
+  }
+  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP, GATE, 2>), grid, dim3(NTHREADS),
                      C::LDS_BYTES, stream, p);
   return st::check_launch("st_conv3x3");
 }
