@@ -211,11 +211,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, O
 
   // ---- epilogue: bias + ReLU, NCHW store (register r of a tile = one channel row) -----
   const int xx = x0 + li;
-  if (p.pool) {
+  if (NT % 2 == 0 && p.pool) {     // (the 2-row-tile instantiation, NT = 1, is never launched with pool)
     // fused MaxPool2d((2,2),(2,2),ceil_mode=True) (generator.py:53,60,73): rows 2k, 2k+1 are two
     // accumulator tiles of this wave, columns 2k, 2k+1 are neighbouring lanes; bias and ReLU commute
     // with the max.  Even lanes write the pooled row (the full-resolution tensor never exists).
-    static_assert(NT % 2 == 0, "row pairs live in one wave");
     const int Hp = (p.Ho + 1) >> 1, Wp = (p.Wo + 1) >> 1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, O
         for (int nt = 0; nt < NT; nt += 2) {
           const int yy = y0 + wp * NT + nt;
           float v = acc[mt][nt][r];
-          if (yy + 1 < p.Ho) v = fmaxf(v, acc[mt][nt + 1][r]);
+          if (yy + 1 < p.Ho) v = fmaxf(v, acc[mt][(nt + 1) % NT][r]);
           const float vn = __shfl_xor(v, 1, 64);
           if (xx + 1 < p.Wo) v = fmaxf(v, vn);
           v += bv;
@@ -328,8 +327,9 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   // round costs more than the third block gains: 512->256 at 64x64, batch 16: 110 vs 124 TFLOP/s); the gated
   // (data-gradient) form and the 32-channel tile need > 168 registers and stay at 2.
   const long long blocks = ptiles * p.ctiles;
-  const bool occ3 = !GATE && MT == 2 && !(blocks > 768 && blocks < 1536);
-  if constexpr (!GATE && MT == 2) {
+  // (the gated form needs 20 B of scratch at 168 registers: worth it on large grids only, +6 % at batch 16, 512 x 512)
+  const bool occ3 = MT == 2 && !(blocks > 768 && blocks < 1536) && (!GATE || blocks >= 1536);
+  if constexpr (MT == 2) {
     if (occ3) {
       hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WM, WP, GATE, 3>), grid, dim3(NTHREADS), C::LDS_BYTES, stream, p);
       return st::check_launch("st_conv3x3");
@@ -342,7 +342,17 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
 
 template <bool GATE>
 int dispatch_conv(ConvParams& p, hipStream_t s) {
-  if (p.cout > 64) return launch_conv<2, 2, 2, 2, GATE>(p, s);   // 128 ch x (4 rows x 32)
+  if (p.cout > 64) {
+    {
+      // small grids (training shapes: 512 -> 512 at 32 x 32, batch 8 = 256 tiles of 4 rows): 2-row tiles double
+      // the number of blocks so that every CU holds 2-3 of them
+      // (measured at batch 8, 256 x 256: 512 -> 256 at 32 x 32, 128 blocks: 0.337 -> 0.197 ms; from 256 blocks up
+      // the 4-row tile is as fast or faster)
+      const long long blocks4 = (long long)p.n * st::cdiv(p.Wo, TW) * st::cdiv(p.Ho, 4) * st::cdiv(p.cout, 128);
+      if (blocks4 <= 192 && !p.pool) return launch_conv<2, 1, 2, 2, GATE>(p, s);
+    }
+    return launch_conv<2, 2, 2, 2, GATE>(p, s);   // 128 ch x (4 rows x 32)
+  }
   if (p.cout > 32) return launch_conv<2, 2, 1, 4, GATE>(p, s);   //  64 ch x (8 rows x 32)
   return launch_conv<1, 4, 1, 4, GATE>(p, s);                    //  32 ch x (16 rows x 32)
 }

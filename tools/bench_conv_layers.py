@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "wgrad"])
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "dgrad_nogate", "wgrad"])
+    ap.add_argument("--pad", default="replicate", choices=["replicate", "zero"])
     ap.add_argument("--compute", default="f32", choices=["f32", "bf16", "bf16x3"])
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -47,7 +48,9 @@ def main():
         if args.mode == "fwd":
             fn = lambda: ops.conv3x3(x, wp, b, cout, upsample2x=up)
         elif args.mode == "dgrad":
-            fn = lambda: ops.conv3x3_dgrad(dy, y, wpt, cin, up, "replicate")
+            fn = lambda: ops.conv3x3_dgrad(dy, y, wpt, cin, up and args.pad == "replicate", args.pad)
+        elif args.mode == "dgrad_nogate":
+            fn = lambda: ops.conv3x3_dgrad(dy, None, wpt, cin, up and args.pad == "replicate", args.pad)
         else:
             fn = lambda: ops.conv3x3_wgrad(x, dy, y, True, up, "replicate", compute=args.compute)
         fn()
