@@ -59,17 +59,37 @@ struct WgradParams {
   int tiles_per_split, nsplit;
 };
 
-template <bool GATE>
+// BO_ output channels x CI_ input channels per block; BO_ / 32 channel tiles x (CI_ * 9 / 32) column tiles are
+// dealt to the 12 waves as (1 channel tile) x (3 column tiles) each: <128, 32> (cout > 64), <64, 64> (cout <= 64:
+// no output-channel rows wasted on padding; narrower M would have to widen N beyond the layer's cin).
+template <int BO_, int CI_>
+struct WShape {
+  static constexpr int OT = BO_ / 32;                  // channel tiles
+  static constexpr int NJT_ = CI_ * 9 / 32;            // column tiles
+  static constexpr int GROUPS = 12 / OT;
+  static_assert(BO_ % 32 == 0 && OT * GROUPS == 12 && NJT_ == GROUPS * WJT, "12 waves x 3 column tiles");
+  static constexpr int G_ELEMS_ = BO_ * GS;
+  static constexpr int X_ELEMS_ = CI_ * PLANE;
+  static constexpr int NXE = CI_ * HR * (TW + 2);      // halo elements
+  static constexpr int NXP_ = (NXE + NTHREADS - 1) / NTHREADS;
+  static constexpr int NG4_ = BO_ * TR * (TW / 4);     // float4 of one dy tile
+  static constexpr int NGP_ = (NG4_ + NTHREADS - 1) / NTHREADS;
+  static constexpr size_t LDS = size_t(G_ELEMS_ + X_ELEMS_) * sizeof(float);
+};
+
+template <bool GATE, int BO_, int CI_>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) {
+  using S = WShape<BO_, CI_>;
+  constexpr int NXP_ = S::NXP_, NGP_ = S::NGP_;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Gs = smem;
-  float* Xs = smem + G_ELEMS;
+  float* Xs = smem + S::G_ELEMS_;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int c0 = blockIdx.x * CI;
-  const int o0 = blockIdx.y * BO;
+  const int c0 = blockIdx.x * CI_;
+  const int o0 = blockIdx.y * BO_;
   const int split = blockIdx.z;
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
@@ -80,17 +100,13 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
   // float4 index g = tid + i*768 -> segment r = g/8 (channel r>>1, tile row r&1), float4 q = g%8.
   const int gq = tid & 7, gr0 = tid >> 3;
   const bool vec4 = (p.W & 3) == 0;   // rows 16-B aligned (the entry point checks the bases)
-  // halo: element e = tid + i*256 of a [CI][HR][TW+2] box, packed as
-  //   bits 0..12 LDS offset, 16..17 row, 20..25 col, 26..30 channel
-  unsigned xinfo[NXP];
-#pragma unroll
-  for (int i = 0; i < NXP; ++i) {
-    const int e = min(tid + i * NTHREADS, CI * HR * (TW + 2) - 1);
-    const int c = e / (HR * (TW + 2));
-    const int rem = e - c * (HR * (TW + 2));
-    const int row = rem / (TW + 2), col = rem - row * (TW + 2);
-    xinfo[i] = unsigned(c * PLANE + row * HC + col) | (row << 16) | (col << 20) | (c << 26);
-  }
+  // halo: element e = tid + i*768 of a [CI_][HR][TW+2] box; (channel, row, col) are recomputed from e with
+  // constant divisors where they are needed (a per-thread table costs NXP_ more registers than the 168 allow)
+#define ST_WG_XE(i_)                                                         \
+  const int e = min(tid + (i_) * NTHREADS, S::NXE - 1);                      \
+  const int c = e / (HR * (TW + 2));                                         \
+  const int rem_ = e - c * (HR * (TW + 2));                                  \
+  const int row = rem_ / (TW + 2), col = rem_ - row * (TW + 2);
   const size_t plane_src = size_t(p.hs) * p.ws;
   const size_t plane_out = size_t(p.H) * p.W;
 
@@ -99,12 +115,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
   for (int t = 0; t < WJT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bias_acc[NGP];
+  float bias_acc[NGP_];
 #pragma unroll
-  for (int i = 0; i < NGP; ++i) bias_acc[i] = 0.f;
+  for (int i = 0; i < NGP_; ++i) bias_acc[i] = 0.f;
 
   // per-lane operand bases.  A: Gs[(ot*32 + li)][pix]; B: column j = jt*32 + li -> (c, tap)
-  const int ot = wave & 3, jt0 = (wave >> 2) * WJT;
+  const int ot = wave % S::OT, jt0 = (wave / S::OT) * WJT;
   const float* aPtr = Gs + (ot * 32 + li) * GS + lh;
   int bOff[WJT];
 #pragma unroll
@@ -123,10 +139,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
     const int x0 = tx * TW, y0 = ty * TR;
 
     // -- global loads (unconditional, clamped addresses) --
-    f32x4 gv[NGP];
+    f32x4 gv[NGP_];
 #pragma unroll
-    for (int i = 0; i < NGP; ++i) {
-      const int r = min(gr0 + (NTHREADS / 8) * i, BO * TR - 1);   // tail threads re-load the last segment
+    for (int i = 0; i < NGP_; ++i) {
+      const int r = min(gr0 + (NTHREADS / 8) * i, BO_ * TR - 1);   // tail threads re-load the last segment
       const int o = min(o0 + (r >> 1), p.cout - 1);
       const int cy = min(y0 + (r & 1), p.H - 1);
       const size_t base = (size_t(b) * p.cout + o) * plane_out + size_t(cy) * p.W;
@@ -147,10 +163,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
         }
       }
     }
-    float xv[NXP];
+    float xv[NXP_];
 #pragma unroll
-    for (int i = 0; i < NXP; ++i) {
-      const int row = (xinfo[i] >> 16) & 3, col = (xinfo[i] >> 20) & 63, c = xinfo[i] >> 26;
+    for (int i = 0; i < NXP_; ++i) {
+      ST_WG_XE(i)
       int cy = min(max(y0 + row - 1, 0), p.H - 1), cx = min(max(x0 + col - 1, 0), p.W - 1);
       if (p.up) { cy >>= 1; cx >>= 1; }
       xv[i] = p.x[(size_t(b) * p.cin + min(c0 + c, p.cin - 1)) * plane_src + size_t(cy) * p.ws + cx];
@@ -158,9 +174,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
 
     __syncthreads();   // previous tile's MFMA phase is done with LDS
 #pragma unroll
-    for (int i = 0; i < NGP; ++i) {
+    for (int i = 0; i < NGP_; ++i) {
       const int r = gr0 + (NTHREADS / 8) * i;
-      if (NG4 % NTHREADS != 0 && r >= BO * TR) break;
+      if (S::NG4_ % NTHREADS != 0 && r >= BO_ * TR) break;
       const bool row_ok = (o0 + (r >> 1)) < p.cout && (y0 + (r & 1)) < p.H;
       float* dst = Gs + (r >> 1) * GS + (r & 1) * TW + gq * 4;
 #pragma unroll
@@ -171,13 +187,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
       }
     }
 #pragma unroll
-    for (int i = 0; i < NXP; ++i) {
-      const int e = tid + i * NTHREADS;
-      const int row = (xinfo[i] >> 16) & 3, col = (xinfo[i] >> 20) & 63, c = xinfo[i] >> 26;
+    for (int i = 0; i < NXP_; ++i) {
+      ST_WG_XE(i)
       const int gy = y0 + row - 1, gx = x0 + col - 1;
       const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       const unsigned m = ((inb || !p.pad_zero) && (c0 + c) < p.cin) ? 0xffffffffu : 0u;
-      if (e < CI * HR * (TW + 2)) Xs[xinfo[i] & 0x1fff] = __uint_as_float(__float_as_uint(xv[i]) & m);
+      if (tid + i * NTHREADS < S::NXE) Xs[c * PLANE + row * HC + col] = __uint_as_float(__float_as_uint(xv[i]) & m);
     }
     __syncthreads();
 
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
   if (p.bias_slabs && blockIdx.x == 0) {
     // a channel's 2 segments x 8 float4 sit in 16 consecutive lanes (tid/8 = 2*ch + row)
 #pragma unroll
-    for (int i = 0; i < NGP; ++i) {
+    for (int i = 0; i < NGP_; ++i) {
       float v = bias_acc[i];
       v += __shfl_xor(v, 1, 64);
       v += __shfl_xor(v, 2, 64);
@@ -217,10 +232,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_kernel(WgradParams p) 
       v += __shfl_xor(v, 8, 64);
       const int r = gr0 + (NTHREADS / 8) * i;
       const int o = o0 + (r >> 1);
-      if ((tid & 15) == 0 && r < BO * TR && o < p.cout) p.bias_slabs[size_t(split) * p.cout + o] = v;
+      if ((tid & 15) == 0 && r < BO_ * TR && o < p.cout) p.bias_slabs[size_t(split) * p.cout + o] = v;
     }
   }
 }
+
+#undef ST_WG_XE
 
 // out[e] = sum_s slabs[s][e], fixed order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs,
@@ -447,13 +464,19 @@ struct Plan {
   int tiles_x, tiles_y, ntiles, nsplit, tiles_per_split;
 };
 
-Plan make_plan(int n, int cout, int cin, int H, int W, int tile_rows = TR) {
+// block shape of the fp32 kernel for a layer (see WShape)
+inline void wgrad_shape(int cout, int* bo, int* ci) {
+  if (cout <= 64) { *bo = 64; *ci = 64; }
+  else { *bo = BO; *ci = CI; }
+}
+
+Plan make_plan(int n, int cout, int cin, int H, int W, int tile_rows = TR, int bo = BO, int ci = CI) {
   Plan pl;
   pl.tiles_x = st::cdiv(W, TW);
   pl.tiles_y = st::cdiv(H, tile_rows);
   const long long nt = (long long)n * pl.tiles_x * pl.tiles_y;
   pl.ntiles = (int)std::min<long long>(nt, 0x7fffffff);
-  const int ctiles = st::cdiv(cin, CI) * st::cdiv(cout, BO);
+  const int ctiles = st::cdiv(cin, ci) * st::cdiv(cout, bo);
   // one block per CU, exactly one round of blocks: measured on MI355X (B = 8, 256^2 and 512^2 decoder
   // shapes) 256 blocks 6.1 ms, 512 blocks 6.8, 1024 blocks 7.9, 384 blocks 8.2 (ragged second round);
   // fewer splits also means fewer partial slabs to write and re-read
@@ -470,7 +493,10 @@ Plan make_plan(int n, int cout, int cin, int H, int W, int tile_rows = TR) {
 extern "C" size_t st_conv3x3_wgrad_workspace_bytes(int n, int cout, int cin, int h, int w) {
   if (n <= 0 || cout <= 0 || cin <= 0 || h <= 0 || w <= 0) return 0;
   // covers both the fp32 (2-row tiles) and the bf16 (4-row tiles) split plans
-  const int nsplit = std::max(make_plan(n, cout, cin, h, w).nsplit, make_plan(n, cout, cin, h, w, bf::TRB).nsplit);
+  int bo, ci;
+  wgrad_shape(cout, &bo, &ci);
+  const int nsplit = std::max(make_plan(n, cout, cin, h, w, TR, bo, ci).nsplit,
+                              make_plan(n, cout, cin, h, w, bf::TRB).nsplit);
   return size_t(nsplit) * (size_t(cout) * cin * 9 + cout) * sizeof(float);
 }
 
@@ -489,7 +515,9 @@ extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_
   const int H = hin << up, W = win << up;
   ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, TR) <= 0x7fffffffLL,
              "st_conv3x3_wgrad: too many pixel tiles");
-  const Plan pl = make_plan(n, cout, cin, H, W);
+  int bo, ci;
+  wgrad_shape(cout, &bo, &ci);
+  const Plan pl = make_plan(n, cout, cin, H, W, TR, bo, ci);
   WgradParams p;
   p.dy = dy; p.ygate = y_gate; p.x = x;
   p.slabs = workspace;
@@ -499,11 +527,17 @@ extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
   p.tiles_per_split = pl.tiles_per_split; p.nsplit = pl.nsplit;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(st::cdiv(cin, CI), st::cdiv(cout, BO), pl.nsplit);
-  if (y_gate)
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel<true>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
-  else
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel<false>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
+  dim3 grid(st::cdiv(cin, ci), st::cdiv(cout, bo), pl.nsplit);
+#define ST_WG_LAUNCH(BO_, CI_)                                                                              \
+  {                                                                                                         \
+    if (y_gate)                                                                                             \
+      hipLaunchKernelGGL((conv3x3_wgrad_kernel<true, BO_, CI_>), grid, dim3(NTHREADS), (WShape<BO_, CI_>::LDS), s, p); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((conv3x3_wgrad_kernel<false, BO_, CI_>), grid, dim3(NTHREADS), (WShape<BO_, CI_>::LDS), s, p); \
+  }
+  if (bo == 64) ST_WG_LAUNCH(64, 64)
+  else ST_WG_LAUNCH(128, 32)
+#undef ST_WG_LAUNCH
   int rc = st::check_launch("st_conv3x3_wgrad");
   if (rc != ST_OK) return rc;
   const long long nw = (long long)cout * cin * 9;
