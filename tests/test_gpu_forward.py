@@ -34,6 +34,17 @@ def ops():
     (1, 64, 3, 40, 48, False, "replicate", False),     # last decoder conv: no ReLU, Cout=3
     (1, 20, 130, 7, 70, False, "zero", False),         # ragged channels
     (1, 16, 40, 1, 1, False, "replicate", True),       # degenerate 1x1 image
+    # the 3-channel layers run on the vector-ALU kernels (csrc/conv3x3_small.hip): ragged tiles, both pads,
+    # 1-pixel images, the upsampled / non-multiple-of-16 shapes that must fall back to the MFMA kernel
+    (2, 3, 64, 17, 33, False, "zero", True),           # loss-VGG conv1_1: zero pad, tile edges in both directions
+    (1, 3, 64, 1, 1, False, "replicate", True),
+    (1, 3, 48, 9, 70, False, "replicate", False),      # cout % 16 == 0 but not 64
+    (1, 3, 40, 9, 9, False, "zero", True),             # cout % 16 != 0 -> MFMA kernel
+    (1, 3, 64, 6, 7, True, "replicate", True),         # upsample -> MFMA kernel
+    (2, 64, 3, 17, 67, False, "zero", True),           # 64 -> 3 with zero pad and ReLU, ragged tiles
+    (1, 128, 3, 33, 130, False, "replicate", False),   # 16 chunks, three column tiles
+    (1, 8, 3, 1, 1, False, "replicate", False),
+    (1, 12, 3, 5, 5, False, "replicate", False),       # cin % 8 != 0 -> MFMA kernel
 ])
 def test_conv3x3(ops, n, cin, cout, h, w, up, pad, relu):
     g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
@@ -86,6 +97,20 @@ def test_adain(ops, hc, wc, hs, ws, alpha):
     np.testing.assert_allclose(st[..., 1], sc.view(2, 6), rtol=1e-5)
     np.testing.assert_allclose(st[..., 2], ms.view(2, 6), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(st[..., 3], ss.view(2, 6), rtol=1e-5)
+
+
+def test_adain_device_eps_matches_host_eps(ops):
+    """st_adain_fwd_dev_eps (eps read from device memory) == st_adain_fwd (eps by value), bit for bit, for the
+    three kernel variants (register, 64-KB planes, 256-KB planes) and the statistics it saves."""
+    g = torch.Generator().manual_seed(3)
+    for (n, c, hc, hs) in ((2, 16, 24, 17), (1, 8, 128, 100), (1, 4, 256, 256)):
+        content = torch.randn(n, c, hc, hc, generator=g).cuda()
+        style = (torch.randn(n, c, hs, hs, generator=g) * 2 + 0.5).cuda()
+        eps = torch.tensor([3.1e-3, 7.7e-2], device="cuda")
+        a, sa = ops.adain(content, style, 3.1e-3, 7.7e-2, 0.7, save_stats=True)
+        b, sb = ops.adain(content, style, 0.0, 0.0, 0.7, save_stats=True, eps_dev=eps)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(sa, sb)
 
 
 def test_adain_golden(ops, golden_dir):
