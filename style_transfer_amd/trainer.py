@@ -141,8 +141,15 @@ class StyleTransferStep:
 
     def forward_losses(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, global_batch: Optional[int] = None):
         with torch.no_grad():                              # frozen encoder: forward only
-            encode_Cfeatures = self.encoder(content_imgs)
-            encode_Sfeatures = self.encoder(style_imgs)
+            if content_imgs.shape == style_imgs.shape:
+                # one pass over [content; style]: same kernels, same per-image results (no cross-image op in
+                # the encoder), twice the grid -- small training batches fill the chip better
+                n = content_imgs.shape[0]
+                feats = self.encoder(torch.cat([content_imgs, style_imgs]))
+                encode_Cfeatures, encode_Sfeatures = feats[:n], feats[n:]
+            else:
+                encode_Cfeatures = self.encoder(content_imgs)
+                encode_Sfeatures = self.encoder(style_imgs)
         transformed_features = self.transformer(encode_Cfeatures, encode_Sfeatures, alpha=1.0)   # trainer.py:433-434
         decode_imgs = self.decoder(transformed_features)
         content_n, style_n = self.norm(content_imgs), self.norm(style_imgs)
