@@ -218,6 +218,135 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(
   }
 }
 
+// ---- weight / bias gradient of a layer with cout == 3 (the decoder's last conv) ------------
+//   dW[o][c][tap] = sum_{n,y,x} G[n][o][y][x] * Xpad[n][c][y+ky-1][x+kx-1],  G = dy (* (y > 0))
+// 1728 outputs, each a reduction over every pixel: on the MFMA weight-gradient kernel the 3 output channels
+// are padded to 64 rows (0.51 ms at batch 8, 256 x 256 for 0.9 GFLOP).  Here a block owns WC = 4 input
+// channels and a range of 16 x 64 pixel tiles; a thread owns 4 consecutive pixels, keeps the 4 x 3 x 9
+// partial sums of its pixels in registers over the whole range (432 FMAs per tile), and the block reduces
+// them once at the end (wave shuffles, then LDS) into a partial slab [split][3][cin * 9], the layout the
+// fixed-order slab reduction of csrc/conv3x3_wgrad.hip sums.  Deterministic, no atomics.
+constexpr int WC = 4;
+
+template <int CO>
+__global__ __launch_bounds__(256) void wgrad_cout_small_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ygate,
+    float* __restrict__ slabs, float* __restrict__ bias_slabs, int n, int cin, int hs, int ws, int H, int W,
+    int up, int pad_zero, int tiles_x, int tiles_y, int ntiles, int tiles_per_split) {
+  __shared__ __attribute__((aligned(16))) float xs[WC * BHR * BLD];
+  __shared__ float red[4][WC * CO * 9 + CO];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * WC, split = blockIdx.y;
+  const int t_begin = split * tiles_per_split, t_end = min(t_begin + tiles_per_split, ntiles);
+  const int row = tid >> 4, col4 = (tid & 15) * 4;
+  const size_t plane_src = size_t(hs) * ws, plane_out = size_t(H) * W;
+
+  float acc[WC][CO][9];
+  float bacc[CO];
+#pragma unroll
+  for (int c = 0; c < WC; ++c)
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[c][o][t] = 0.f;
+#pragma unroll
+  for (int o = 0; o < CO; ++o) bacc[o] = 0.f;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    int rem = t;
+    const int tx = rem % tiles_x;
+    rem /= tiles_x;
+    const int ty = rem % tiles_y;
+    const int b = rem / tiles_y;
+    const int x0 = tx * BTW, y0 = ty * BTH;
+    // halo of WC channels -> LDS (edge replicate / zero pad / x2-upsample source index in the address)
+    float st_[WC][BNP];
+    unsigned loff[BNP], smask[BNP];
+#pragma unroll
+    for (int i = 0; i < BNP; ++i) {
+      const int idx = min(tid + i * 256, BHR * BHC - 1);
+      const int r = idx / BHC, cc = idx - r * BHC;
+      const int gy = y0 + r - 1, gx = x0 + cc - 1;
+      const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      if (up) { cy >>= 1; cx >>= 1; }
+      loff[i] = unsigned(r * BLD + cc);
+      smask[i] = (inb || !pad_zero) ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int c = 0; c < WC; ++c)
+        st_[c][i] = x[(size_t(b) * cin + min(c0 + c, cin - 1)) * plane_src + size_t(cy) * ws + cx];
+    }
+    // this thread's 4 pixels of the CO gradient planes (zero outside the image)
+    float g[CO][4];
+    const int oy = y0 + row, ox = x0 + col4;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const size_t base = (size_t(b) * CO + o) * plane_out + size_t(min(oy, H - 1)) * W;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = oy < H && ox + q < W;
+        const size_t at = base + min(ox + q, W - 1);
+        float v = dy[at];
+        if (ygate) v = ygate[at] > 0.f ? v : 0.f;
+        g[o][q] = ok ? v : 0.f;
+      }
+    }
+    __syncthreads();                                  // previous tile's reads are done
+#pragma unroll
+    for (int c = 0; c < WC; ++c)
+#pragma unroll
+      for (int i = 0; i < BNP; ++i)
+        if (BHR * BHC % 256 == 0 || tid + i * 256 < BHR * BHC)
+          xs[c * (BHR * BLD) + loff[i]] = __uint_as_float(__float_as_uint(st_[c][i]) & smask[i]);
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < CO; ++o) bacc[o] += (g[o][0] + g[o][1]) + (g[o][2] + g[o][3]);
+#pragma unroll
+    for (int c = 0; c < WC; ++c) {
+      float v[3][6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float* rp = xs + c * (BHR * BLD) + (row + r) * BLD + col4;
+        const float4 a = *reinterpret_cast<const float4*>(rp);
+        const float2 e = *reinterpret_cast<const float2*>(rp + 4);
+        v[r][0] = a.x; v[r][1] = a.y; v[r][2] = a.z; v[r][3] = a.w; v[r][4] = e.x; v[r][5] = e.y;
+      }
+#pragma unroll
+      for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[c][o][tap] = fmaf(g[o][q], v[tap / 3][q + tap % 3], acc[c][o][tap]);
+    }
+  }
+
+  // block reduction: 64-lane shuffle tree per value, then the 4 wave sums through LDS (fixed order)
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < WC; ++c)
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = st::wave_sum(acc[c][o][tap]);
+        if (lane == 0) red[wave][(c * CO + o) * 9 + tap] = v;
+      }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    const float v = st::wave_sum(bacc[o]);
+    if (lane == 0) red[wave][WC * CO * 9 + o] = v;
+  }
+  __syncthreads();
+  if (tid < WC * CO * 9) {
+    const int c = tid / (CO * 9), o = (tid / 9) % CO, tap = tid % 9;
+    const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (c0 + c < cin) slabs[(size_t(split) * CO + o) * cin * 9 + size_t(c0 + c) * 9 + tap] = v;
+  } else if (tid < WC * CO * 9 + CO && bias_slabs && blockIdx.x == 0) {
+    bias_slabs[size_t(split) * CO + (tid - WC * CO * 9)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+}
+
 }  // namespace
 
 namespace st {
@@ -245,6 +374,29 @@ bool conv3x3_small_fwd(const float* x, const float* w_packed, const float* bias,
     return true;
   }
   return false;
+}
+
+// Weight / bias gradient of a cout == 3 layer.  Plan: *nsplit partial slabs [nsplit][3][cin*9] (+ [nsplit][3] bias
+// slabs) that the caller sums with its fixed-order slab reduction.
+int wgrad_small_nsplit(int n, int cout, int cin, int H, int W) {
+  if (cout != 3) return 0;
+  const long long ntiles = (long long)n * cdiv(W, BTW) * cdiv(H, BTH);
+  if (ntiles > 0x7fffffffLL) return 0;
+  const int chunks = cdiv(cin, WC);
+  int nsplit = (int)std::max<long long>(1, std::min<long long>(ntiles, cdiv(1024, chunks)));
+  const int per = cdiv((int)ntiles, nsplit);
+  return cdiv((int)ntiles, per);
+}
+
+int wgrad_small_launch(const float* x, const float* dy, const float* ygate, float* slabs, float* bias_slabs, int n,
+                       int cin, int hs, int ws, int H, int W, int up, int pad_zero, hipStream_t s) {
+  const int tiles_x = cdiv(W, BTW), tiles_y = cdiv(H, BTH);
+  const int ntiles = n * tiles_x * tiles_y;
+  const int nsplit = wgrad_small_nsplit(n, 3, cin, H, W);
+  const int per = cdiv(ntiles, nsplit);
+  hipLaunchKernelGGL(wgrad_cout_small_kernel<3>, dim3(cdiv(cin, WC), nsplit), dim3(256), 0, s, x, dy, ygate, slabs,
+                     bias_slabs, n, cin, hs, ws, H, W, up, pad_zero, tiles_x, tiles_y, ntiles, per);
+  return check_launch("st_conv3x3_wgrad(cout=3)");
 }
 
 }  // namespace st

@@ -490,13 +490,41 @@ Plan make_plan(int n, int cout, int cin, int H, int W, int tile_rows = TR, int b
 
 }  // namespace
 
+namespace st {
+// csrc/conv3x3_small.hip: vector-ALU weight gradient of the 3-output-channel layer
+int wgrad_small_nsplit(int n, int cout, int cin, int H, int W);
+int wgrad_small_launch(const float* x, const float* dy, const float* ygate, float* slabs, float* bias_slabs, int n,
+                       int cin, int hs, int ws, int H, int W, int up, int pad_zero, hipStream_t s);
+}  // namespace st
+
+// cout == 3: the vector-ALU kernel writes its partial slabs, the fixed-order reduction below sums them
+static int wgrad_small(const float* x, const float* dy, const float* y_gate, float* dw, float* dbias,
+                       float* workspace, int n, int cin, int hin, int win, int cout, int up, int pad_mode,
+                       hipStream_t s, bool* handled) {
+  const int H = hin << up, W = win << up;
+  const int nsplit = st::wgrad_small_nsplit(n, cout, cin, H, W);
+  *handled = nsplit > 0;
+  if (!*handled) return ST_OK;
+  float* bias_slabs = dbias ? workspace + size_t(nsplit) * cout * cin * 9 : nullptr;
+  int rc = st::wgrad_small_launch(x, dy, y_gate, workspace, bias_slabs, n, cin, hin, win, H, W, up,
+                                  pad_mode == ST_PAD_ZERO, s);
+  if (rc != ST_OK) return rc;
+  const long long nw = (long long)cout * cin * 9;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(nw, 256), 2048)),
+                     dim3(256), 0, s, workspace, dw, nw, nsplit);
+  if (dbias)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, s, bias_slabs, dbias, (long long)cout, nsplit);
+  return st::check_launch("st_conv3x3_wgrad(cout=3, reduce)");
+}
+
 extern "C" size_t st_conv3x3_wgrad_workspace_bytes(int n, int cout, int cin, int h, int w) {
   if (n <= 0 || cout <= 0 || cin <= 0 || h <= 0 || w <= 0) return 0;
   // covers both the fp32 (2-row tiles) and the bf16 (4-row tiles) split plans
   int bo, ci;
   wgrad_shape(cout, &bo, &ci);
-  const int nsplit = std::max(make_plan(n, cout, cin, h, w, TR, bo, ci).nsplit,
-                              make_plan(n, cout, cin, h, w, bf::TRB).nsplit);
+  const int nsplit = std::max({make_plan(n, cout, cin, h, w, TR, bo, ci).nsplit,
+                               make_plan(n, cout, cin, h, w, bf::TRB).nsplit,
+                               st::wgrad_small_nsplit(n, cout, cin, h, w)});
   return size_t(nsplit) * (size_t(cout) * cin * 9 + cout) * sizeof(float);
 }
 
@@ -513,6 +541,12 @@ extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_
              "st_conv3x3_wgrad: dy / y_gate must be 16-byte aligned");
   const int up = upsample2x ? 1 : 0;
   const int H = hin << up, W = win << up;
+  {
+    bool handled = false;
+    const int rc_small = wgrad_small(x, dy, y_gate, dw, dbias, workspace, n, cin, hin, win, cout, up, pad_mode,
+                                     (hipStream_t)stream, &handled);
+    if (handled) return rc_small;
+  }
   ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, TR) <= 0x7fffffffLL,
              "st_conv3x3_wgrad: too many pixel tiles");
   int bo, ci;
@@ -562,6 +596,12 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
              "st_conv3x3_wgrad_bf16: dy / y_gate must be 16-byte aligned");
   const int up = upsample2x ? 1 : 0;
   const int H = hin << up, W = win << up;
+  {
+    bool handled = false;
+    const int rc_small = wgrad_small(x, dy, y_gate, dw, dbias, workspace, n, cin, hin, win, cout, up, pad_mode,
+                                     (hipStream_t)stream, &handled);
+    if (handled) return rc_small;
+  }
   ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, bf::TRB) <= 0x7fffffffLL,
              "st_conv3x3_wgrad_bf16: too many pixel tiles");
   const Plan pl = make_plan(n, cout, cin, H, W, bf::TRB);

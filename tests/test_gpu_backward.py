@@ -32,6 +32,12 @@ def ref_layer(x, w, b, up, pad, relu):
     (2, 20, 130, 7, 70, False, "zero", False),         # ragged channels
     (1, 32, 40, 1, 1, False, "replicate", True),       # 1x1 image: all nine taps fold onto one pixel
     (1, 16, 16, 2, 64, True, "replicate", True),
+    # cout == 3: the vector-ALU weight-gradient kernel (csrc/conv3x3_small.hip): ragged tiles, gate, zero pad,
+    # upsampled input, cin not a multiple of its 4-channel block, several tiles per split
+    (2, 64, 3, 17, 67, False, "zero", True),
+    (1, 6, 3, 33, 130, False, "replicate", True),
+    (1, 8, 3, 9, 5, True, "replicate", False),
+    (3, 16, 3, 40, 70, False, "replicate", False),
 ])
 def test_conv_backward(n, cin, cout, h, w, up, pad, relu):
     from style_transfer_amd import ops
