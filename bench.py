@@ -55,8 +55,9 @@ DOMINANT_BF16 = "conv3x3_bf16_kernel<2,4,2,4>"
 DOMINANT_BF16X3 = "conv3x3_bf16x3_kernel<1,4,2,4>"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 # HBM bytes per launch of the dominant kernel from profiles/r1_bench_infer_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
-# KiB, averaged over its 20 launches per inference step; 4-B-per-lane loads: FETCH_SIZE taken as reported)
-DOMINANT_TRAFFIC_BYTES = (529644.5 + 239206.4) * 1024
+# KiB, averaged over the launches of its 3-blocks-per-CU instantiation (19 of the 20 launches per inference step);
+# 4-B-per-lane loads: FETCH_SIZE taken as reported)
+DOMINANT_TRAFFIC_BYTES = (568943.2 + 248346.9) * 1024
 
 
 def encoder_decoder_flops(side: int):
