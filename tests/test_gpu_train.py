@@ -170,3 +170,46 @@ def test_hip_graph_replay_matches_eager_steps():
         assert abs(a - b) <= 1e-5 * abs(a), (t0, t1)
     for a, b in zip(d0 + a0, d1 + a1):
         assert rel_l2(b, a) < 1e-5
+
+
+def test_trainer_loop_with_hip_graph_matches_eager(tmp_path, monkeypatch):
+    """Trainer.train with use_hip_graph=True (GraphedStep inside the real loop: cosine LR schedule stepping the
+    device-resident learning rate, gradient clamp, checkpoint written with the capturable optimizer, resume) gives
+    the same epoch losses as the same loop with the capture switched off (WARMUP never reached: every step eager,
+    same capturable optimizer arithmetic)."""
+    from style_transfer_amd.trainer import Trainer, GraphedStep
+
+    class Loader(list):
+        dataset = list(range(12))
+
+    g = torch.Generator().manual_seed(4)
+    batches = Loader([{"content_image": torch.rand(2, 3, 48, 48, generator=g),
+                       "style_image": torch.rand(2, 3, 48, 48, generator=g)} for _ in range(6)])
+    import warnings
+    hists = []
+    for graph in (False, True):
+        kw = dict(output_dir=str(tmp_path / f"g{int(graph)}"), num_train_epochs=2, per_device_batch_size=2,
+                  learning_rate=1e-3, alpha=1.0, beta=10.0, gamma=1.0, delta=10.0, eps=0.1, save_best=False,
+                  do_decoder_train=True, optim_name={"optim_name": "adam"}, gradient_threshold=5.0,
+                  content_layers_idx=[21], style_layers_idx=[2, 7, 14, 19, 25],
+                  encoder_weights=R.make_encoder_state(0),
+                  decoder_weights={k.removeprefix("decoder."): v for k, v in R.make_decoder_state(1).items()},
+                  vgg_weights=R.make_loss_vgg_state(2, upto=25), use_pretrained_WCTDECODER=True, use_hip_graph=True)
+        monkeypatch.setattr(GraphedStep, "WARMUP", 3 if graph else 10 ** 9)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            hists.append(Trainer({"train": batches}, **kw).train())
+    eager, graphed = hists
+    assert len(graphed) == 2
+    for a, b in zip(eager, graphed):
+        for k in ("content", "style", "variation", "hist", "total"):
+            assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-6), (k, a[k], b[k])
+    ckpts = sorted((tmp_path / "g1").glob("TotalL_*/transformer12.pth"))
+    assert ckpts
+    last = max(ckpts, key=lambda p: torch.load(p, map_location="cpu", weights_only=True)["epoch"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkeypatch.setattr(GraphedStep, "WARMUP", 3)
+        kw2 = dict(kw, num_train_epochs=3, resume_from_checkpoint=str(last), output_dir=str(tmp_path / "resumed"))
+        hist2 = Trainer({"train": batches}, **kw2).train()
+    assert [h["epoch"] for h in hist2] == [2] and hist2[0]["total"] == hist2[0]["total"]
