@@ -122,6 +122,16 @@ int st_conv3x3_fwd_bf16(const float* x, const void* w_packed, const float* bias,
 int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, const float* bias, float* ypool,
                              int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
                              st_stream_t stream);
+/* bf16 mode, layer-to-layer form: the activation on either side may be in the channel-group layout "G8" =
+ * bf16 [n][c/8][h][w][8] (x_g8 / y_g8 != 0; 0 = fp32 NCHW as above).  The conv -> conv hand-overs inside one
+ * Sequential (generator.py:47-76, 89-117) then move 2 instead of 4 bytes per value, a G8 input is staged by
+ * LDS-DMA, and the results are bit-identical to chaining st_conv3x3_fwd_bf16 / st_conv3x3_pool_fwd_bf16 (a G8
+ * output is the round-to-nearest-even the next layer's staging applies anyway).  pool != 0: fused ceil-mode 2x2
+ * max pool (not with upsample2x).  A G8 input needs cin % 16 == 0 and replicate padding, a G8 output
+ * cout % 8 == 0; G8 buffers must be 16-byte aligned.  Forward only. */
+int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y, int y_g8,
+                           int n, int cin, int hin, int win, int cout, int upsample2x, int pad_mode, int relu,
+                           int pool, st_stream_t stream);
 /* workspace: st_conv3x3_dgrad_workspace_bytes() (same as the fp32 entry point) */
 int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t, float* dx,
                           float* workspace, const float* dx_gate, int n, int cout, int h, int w, int cin,

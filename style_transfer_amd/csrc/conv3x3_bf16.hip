@@ -52,6 +52,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct ConvParams {
   const float* x;
@@ -84,7 +86,10 @@ struct Cfg {
   static constexpr int W_UNITS = NPART * 9 * BM * 2;   // 16-B units of the weight slab: [part][tap][half][BM]
   static constexpr int NWI = W_UNITS / 64;        // 1-KiB LDS-DMA wave instructions per weight slab
   static constexpr int NW = (NWI + 7) / 8;        // ... per wave
-  static constexpr int X_UNITS = NPART * NITEM;  // 16-B units of the halo image: [part][half][position]
+  // 16-B units of the halo image: [part][half][position], rounded up to whole 1-KiB LDS-DMA pieces
+  static constexpr int X_UNITS = (NPART * NITEM + 63) / 64 * 64;
+  static constexpr int NXI = (NITEM + 63) / 64;   // XG: 1-KiB LDS-DMA wave instructions per halo image
+  static constexpr int NXW = (NXI + 7) / 8;       // ... per wave
   static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + 2 * X_UNITS) * 16;   // both double-buffered
 };
 
@@ -97,10 +102,20 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
 
 // TAIL: cin is not a multiple of 16 (the 3-channel layers): channel indices are clamped per load
 // and the missing channels masked to zero.
-template <int MT, int NT, int WM, int WP, bool GATE, bool TAIL, bool SPLIT, bool PIPE>
+//
+// XG / YG: the input / output activation is in the channel-group layout "G8" -- bf16 [n][c/8][h][w][8], the form
+// the layers of one network hand to each other in bf16 mode (st_conv3x3_fwd_bf16_g8).  A G8 pixel of one channel
+// group is the 16-B unit of the LDS halo image, so an XG kernel stages its input by LDS-DMA like the weights (no
+// registers, no conversion, half the bytes of the fp32 form); a YG kernel rounds its result to bf16 (the same
+// round-to-nearest-even the next layer's staging would apply to an fp32 result: the chain is bit-identical to the
+// fp32-activation form) and writes 16 B per pixel and channel group.
+template <int MT, int NT, int WM, int WP, bool GATE, bool TAIL, bool SPLIT, bool PIPE, bool XG = false,
+          bool YG = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p) {
   using C = Cfg<MT, NT, WM, WP, SPLIT>;
   static_assert(WM * WP == 8, "eight waves per block");
+  static_assert(!XG || (!GATE && !TAIL && !SPLIT), "G8 input: plain forward form only");
+  static_assert(!YG || !SPLIT, "G8 output: bf16 mode only");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   u32x4* Ws = smem16;                     // 2 x [part][tap][half][BM]   (filled by LDS-DMA)
   u32x4* Xs = smem16 + 2 * C::W_UNITS;    // 2 x [part][half][position]
@@ -140,8 +155,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   unsigned soff[C::NP];    // element offset of the item's first channel inside the chunk
   unsigned smask[C::NP];   // all-ones: keep; 0: zero padding
   int half_[C::NP];
+  // XG: wave w copies 1-KiB pieces u = i*8 + w of the halo image; lane -> 16-B unit (half, position) u*64 + lane,
+  // source = the (clamped, optionally upsampled) pixel of channel group 2*chunk + half
+  unsigned xoff[XG ? C::NXW : 1];
+  const u32x4* xg = reinterpret_cast<const u32x4*>(p.x) + size_t(b) * (p.cin / 8) * plane_src;
+  if constexpr (XG) {
 #pragma unroll
-  for (int i = 0; i < C::NP; ++i) {
+    for (int i = 0; i < C::NXW; ++i) {
+      const int idx = min((i * 8 + wave) * 64 + lane, C::NITEM - 1);
+      const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;
+      const int r = pidx / HC, cc = pidx - r * HC;
+      int cy = min(max(y0 + r - 1, 0), p.H - 1), cx = min(max(x0 + cc - 1, 0), p.W - 1);
+      if (p.up) { cy >>= 1; cx >>= 1; }
+      xoff[i] = unsigned(half) * unsigned(plane_src) + unsigned(cy * p.ws + cx);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (XG ? 0 : C::NP); ++i) {
     const int idx = min(tid + i * NTHREADS, C::NITEM - 1);
     const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;
     const int r = pidx / HC, cc = pidx - r * HC;
@@ -360,6 +390,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     if (MORE2_) { ST_BARRIER_KEEP_LOADS(); } else { ST_BARRIER_DRAIN(); }                  \
   }
 
+  // XG: halo image of chunk_ -> X buffer (chunk_ & 1) by LDS-DMA
+#define ST_ISSUE_XG(chunk_)                                                                \
+  {                                                                                        \
+    const u32x4* xsrc = xg + size_t(chunk_) * 2 * plane_src;                               \
+    u32x4* xdst = Xs + ((chunk_) & 1) * C::X_UNITS;                                        \
+    _Pragma("unroll") for (int i = 0; i < C::NXW; ++i) {                                   \
+      const int u = i * 8 + wave;                                                          \
+      if (C::NXI % 8 == 0 || u < C::NXI)                                                   \
+        __builtin_amdgcn_global_load_lds(                                                  \
+            (const __attribute__((address_space(1))) void*)(xsrc + xoff[i]),               \
+            (__attribute__((address_space(3))) void*)(xdst + u * 64), 16, 0, 0);           \
+    }                                                                                      \
+  }
+  // One chunk of an XG kernel: both operands of chunk c+1 arrive by LDS-DMA while the 9 taps of chunk c run with
+  // the operand reads of tap t+1 issued before the MFMAs of tap t.
+#define ST_CHUNK_DMA(chunk_, MORE1_)                                                       \
+  {                                                                                        \
+    ST_READ_TAP(chunk_, 0, 0);                                                             \
+    if (MORE1_) { ST_ISSUE_W((chunk_) + 1); ST_ISSUE_XG((chunk_) + 1); }                   \
+    asm volatile("" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                        \
+      if (t < 8) ST_READ_TAP(chunk_, t + 1, (t + 1) & 1);                                  \
+      ST_MFMA_TAP(t & 1);                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+    }                                                                                      \
+    ST_BARRIER_DRAIN();                                                                    \
+  }
+
   // Workgroup barrier that does NOT drain the register loads issued after the LDS-DMA pieces:
   // vmcnt is in order, so allowing the NLOADS youngest operations to stay in flight still
   // retires every older LDS-DMA (the counter saturates at 63: a larger NLOADS only waits for a
@@ -389,11 +448,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   const bool lead = __builtin_amdgcn_readfirstlane(wave) < 4;
   const int nch = p.nchunks;
   ST_ISSUE_W(0);
-  ST_LOAD_X(0);
-  ST_STORE_X(0);
-  if (nch > 1) ST_LOAD_X(1);
+  if constexpr (XG) {
+    ST_ISSUE_XG(0);
+  } else {
+    ST_LOAD_X(0);
+    ST_STORE_X(0);
+    if (nch > 1) ST_LOAD_X(1);
+  }
   ST_BARRIER_DRAIN();
-  if constexpr (PIPE) {
+  if constexpr (XG) {
+    bf16x8 pa[2][MT], pb[2][NT], pal[1][MT], pbl[1][NT];
+    int chunk = 0;
+    for (; chunk + 1 < nch; ++chunk) ST_CHUNK_DMA(chunk, true);
+    ST_CHUNK_DMA(chunk, false);
+  } else if constexpr (PIPE) {
     bf16x8 pa[2][MT], pb[2][NT], pal[SPLIT ? 2 : 1][MT], pbl[SPLIT ? 2 : 1][NT];
     int chunk = 0;
     for (; chunk + 2 < nch; ++chunk) ST_CHUNK_PIPE(chunk, true, true);
@@ -422,7 +490,91 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // becomes store-ISSUE-bound.  Each wave therefore transposes a tile through a private 4 KB LDS
   // patch (the staging buffers are free after the last barrier) and writes 16 B per lane: 8 lanes
   // cover one 128-B row segment, a wave instruction writes 8 channel rows.
-  if (p.pool) {
+  if constexpr (YG) {
+    // G8 bf16 output: a wave turns each 32 ch x 32 px accumulator tile into [32 px][4 groups][8 ch] bf16 through a
+    // private 2 KB LDS patch (lanes l and l+32 hold the two halves of a pixel's 8-channel group) and stores 16 B
+    // per lane: 32 lanes cover 512 contiguous bytes of one channel group's row.
+    unsigned* patch = reinterpret_cast<unsigned*>(smem16 + wave * 128);
+    const u32x4* patch16 = reinterpret_cast<const u32x4*>(patch);
+    u32x4* yg = reinterpret_cast<u32x4*>(p.y);
+    const int cgroups = p.cout >> 3;
+    const bool pool = p.pool != 0;
+    const int Hy = pool ? (p.Ho + 1) >> 1 : p.Ho, Wy = pool ? (p.Wo + 1) >> 1 : p.Wo;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int cbase = m0 + wm * (MT * 32) + mt * 32;
+      float bv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bv[r] = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+      }
+      if (!pool) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int yy = y0 + wp * NT + nt;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[mt][nt][q * 4 + j] + bv[q * 4 + j];
+              if (p.relu) v = fmaxf(v, 0.f);
+              h[j] = (__bf16)v;
+            }
+            const u32x2 hv = __builtin_bit_cast(u32x2, h);
+            patch[(li * 4 + q) * 4 + lh * 2 + 0] = hv[0];
+            patch[(li * 4 + q) * 4 + lh * 2 + 1] = hv[1];
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int q = k * 2 + lh;
+            const u32x4 v = patch16[li * 4 + q];
+            const int cg = (cbase >> 3) + q, xs = x0 + li;
+            if (cg < cgroups && yy < p.Ho && xs < p.Wo)
+              yg[((size_t(b) * cgroups + cg) * Hy + yy) * Wy + xs] = v;
+          }
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        // fused MaxPool2d((2,2),(2,2),ceil_mode=True): rounding is monotonic, so max-then-round equals the
+        // pool of the rounded activation
+#pragma unroll
+        for (int nt = 0; nt + 1 < NT; nt += 2) {
+          const int yy = y0 + wp * NT + nt;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[mt][nt][q * 4 + j];
+              if (yy + 1 < p.Ho) v = fmaxf(v, acc[mt][nt + 1][q * 4 + j]);
+              const float vn = __shfl_xor(v, 1, 64);
+              if (x0 + li + 1 < p.Wo) v = fmaxf(v, vn);
+              v += bv[q * 4 + j];
+              if (p.relu) v = fmaxf(v, 0.f);
+              h[j] = (__bf16)v;
+            }
+            const u32x2 hv = __builtin_bit_cast(u32x2, h);
+            if (!(li & 1)) {
+              patch[((li >> 1) * 4 + q) * 4 + lh * 2 + 0] = hv[0];
+              patch[((li >> 1) * 4 + q) * 4 + lh * 2 + 1] = hv[1];
+            }
+          }
+          asm volatile("" ::: "memory");
+          {
+            const int q = lane >> 4, px = lane & 15;
+            const u32x4 v = patch16[px * 4 + q];
+            const int cg = (cbase >> 3) + q;
+            if (cg < cgroups && yy < p.Ho && x0 + 2 * px < p.Wo)
+              yg[((size_t(b) * cgroups + cg) * Hy + (yy >> 1)) * Wy + (x0 >> 1) + px] = v;
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+  } else if (p.pool) {
     // fused MaxPool2d((2,2),(2,2),ceil_mode=True) (generator.py:53,60,73), as in csrc/conv3x3.hip
     static_assert(NT % 2 == 0, "row pairs live in one wave");
     const int Hp = (p.Ho + 1) >> 1, Wp = (p.Wo + 1) >> 1;
@@ -512,6 +664,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #undef ST_SLICE
 #undef ST_CHUNK_PIPE
 #undef ST_ISSUE_W
+#undef ST_ISSUE_XG
+#undef ST_CHUNK_DMA
 #undef ST_LOAD_X
 #undef ST_STORE_X
 #undef ST_MFMA
@@ -567,6 +721,35 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false, SPLIT, !GATE>), grid, dim3(NTHREADS),
                        C::LDS_BYTES, stream, p);
   return st::check_launch("st_conv3x3_bf16");
+}
+
+// G8 forms (st_conv3x3_fwd_bf16_g8): xg / yg select the activation layout on either side
+template <int MT, int NT, int WM, int WP>
+int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
+  using C = Cfg<MT, NT, WM, WP, false>;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "LDS image exceeds the CU's 160 KB");
+  p.tiles_x = st::cdiv(p.Wo, TW);
+  p.tiles_y = st::cdiv(p.Ho, C::TH);
+  p.ablate = 0;
+  const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
+  p.ctiles = st::cdiv(p.cout, C::BM);
+  ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3_fwd_bf16_g8: too many tiles (%lld)", ptiles * p.ctiles);
+  p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
+  p.vec_store = (p.ldo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
+  dim3 grid((unsigned)(ptiles * p.ctiles));
+  if (xg && yg)
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, false, true, true>), grid,
+                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+  else if (xg)
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, false, true, false>), grid,
+                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+  else if (p.cin % KC != 0)
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, true, false, false, false, true>), grid,
+                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, true, false, true>), grid,
+                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+  return st::check_launch("st_conv3x3_fwd_bf16_g8");
 }
 
 template <bool GATE>
@@ -662,6 +845,40 @@ extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, co
                                         int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
                                         st_stream_t stream) {
   return conv3x3_fwd_bf16_impl(x, w_packed, bias, ypool, n, cin, hin, win, cout, 0, pad_mode, relu, 1, stream);
+}
+
+extern "C" int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
+                                      int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
+                                      int pad_mode, int relu, int pool, st_stream_t stream) {
+  ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16_g8: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
+             "st_conv3x3_fwd_bf16_g8: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO, "st_conv3x3_fwd_bf16_g8: bad pad_mode %d",
+             pad_mode);
+  ST_REQUIRE(!(pool && upsample2x), "st_conv3x3_fwd_bf16_g8: pool and upsample2x exclude each other");
+  if (!x_g8 && !y_g8)
+    return conv3x3_fwd_bf16_impl((const float*)x, w_packed, bias, (float*)y, n, cin, hin, win, cout, upsample2x,
+                                 pad_mode, relu, pool, stream);
+  ST_REQUIRE(!x_g8 || (cin % KC == 0 && pad_mode == ST_PAD_REPLICATE),
+             "st_conv3x3_fwd_bf16_g8: a G8 input needs cin %% 16 == 0 (got %d) and replicate padding", cin);
+  ST_REQUIRE(!x_g8 || reinterpret_cast<uintptr_t>(x) % 16 == 0, "st_conv3x3_fwd_bf16_g8: x must be 16-byte aligned");
+  ST_REQUIRE(!y_g8 || cout % 8 == 0, "st_conv3x3_fwd_bf16_g8: a G8 output needs cout %% 8 == 0 (got %d)", cout);
+  ST_REQUIRE(!y_g8 || reinterpret_cast<uintptr_t>(y) % 16 == 0, "st_conv3x3_fwd_bf16_g8: y must be 16-byte aligned");
+  ST_REQUIRE((long long)hin * win * 16 < (1LL << 31), "st_conv3x3_fwd_bf16_g8: plane too large");
+  ConvParams p;
+  p.x = (const float*)x; p.gate = nullptr; p.wp = (const u32x4*)w_packed; p.bias = bias; p.y = (float*)y;
+  p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
+  p.up = upsample2x ? 1 : 0;
+  p.H = hin << p.up; p.W = win << p.up;
+  p.Ho = p.H; p.Wo = p.W; p.ldo = p.W; p.shift = 0; p.pool = pool ? 1 : 0;
+  p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
+  p.nchunks = st::cdiv(cin, KC);
+  p.pad_zero = pad_mode == ST_PAD_ZERO;
+  p.relu = relu ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (cout > 64) return launch_conv_g8<2, 4, 2, 4>(p, x_g8 != 0, y_g8 != 0, s);   // 128 ch x (16 rows x 32)
+  if (cout > 32) return launch_conv_g8<2, 4, 1, 8>(p, x_g8 != 0, y_g8 != 0, s);   //  64 ch x (32 rows x 32)
+  return launch_conv_g8<1, 4, 1, 8>(p, x_g8 != 0, y_g8 != 0, s);                  //  32 ch x (32 rows x 32)
 }
 
 extern "C" int st_conv3x3_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y,

@@ -163,6 +163,62 @@ def conv3x3_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.T
     return y
 
 
+def to_g8(x: torch.Tensor) -> torch.Tensor:
+    """fp32 NCHW -> the bf16 channel-group layout [n, c/8, h, w, 8] ("G8", include/st_hip.h) by torch ops
+    (round-to-nearest-even, like the kernels); c % 8 == 0."""
+    n, c, h, w = x.shape
+    assert c % 8 == 0, f"G8 needs c % 8 == 0, got {c}"
+    return x.view(n, c // 8, 8, h, w).permute(0, 1, 3, 4, 2).to(torch.bfloat16).contiguous()
+
+
+def from_g8(g: torch.Tensor) -> torch.Tensor:
+    """G8 bf16 [n, c/8, h, w, 8] -> fp32 NCHW (exact)."""
+    n, cg, h, w, e = g.shape
+    assert e == 8 and g.dtype == torch.bfloat16
+    return g.permute(0, 1, 4, 2, 3).reshape(n, cg * 8, h, w).float().contiguous()
+
+
+def is_g8(x: torch.Tensor) -> bool:
+    return x.dim() == 5 and x.dtype == torch.bfloat16 and x.shape[-1] == 8
+
+
+def conv3x3_g8(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+               upsample2x: bool = False, pad_mode="replicate", relu: bool = True, pool: bool = False,
+               y_g8: bool = True) -> torch.Tensor:
+    """bf16-mode conv with the layer-to-layer activation layout G8 on either side (st_conv3x3_fwd_bf16_g8):
+    ``x`` is fp32 NCHW or a G8 tensor (is_g8); the result is G8 when ``y_g8`` else fp32 NCHW.  Bit-identical
+    to conv3x3 / conv3x3_pool with bf16-packed weights on the same values.  Forward only."""
+    lib = _lib.load()
+    x_g8 = is_g8(x)
+    if x_g8:
+        n, cg, h, w, _ = (int(v) for v in x.shape)
+        cin = cg * 8
+    else:
+        assert x.dim() == 4 and x.dtype == torch.float32, "conv3x3_g8 expects fp32 NCHW or a G8 tensor"
+        n, cin, h, w = (int(v) for v in x.shape)
+    assert x.is_contiguous()
+    fam = conv_family(w_packed, cout, cin)
+    assert fam == "bf16", "conv3x3_g8 needs bf16-packed weights"
+    s = 2 if upsample2x else 1
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h * s, w * s)
+    if y_g8:
+        y = torch.empty((n, cout // 8, ho, wo, 8), dtype=torch.bfloat16, device=x.device)
+    else:
+        y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cout, "bf16"), 2.0 * n * h * s * w * s * cin * cout * 9,
+                                 float(x.numel() * x.element_size() + y.numel() * y.element_size()))
+    _lib.check(lib.st_conv3x3_fwd_bf16_g8(
+        _lib.dev_ptr(x, "x", x.dtype), int(x_g8), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
+        _lib.dev_ptr(bias, "bias") if bias is not None else None, _lib.dev_ptr(y, "y", y.dtype), int(y_g8),
+        n, cin, h, w, cout, int(upsample2x), _pad_code(pad_mode), int(relu), int(pool), _lib.stream_ptr()),
+        "st_conv3x3_fwd_bf16_g8")
+    if ev is not None:
+        ev.record()
+    return y
+
+
 def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: torch.Tensor, cin: int,
                   upsample2x: bool = False, pad_mode="replicate",
                   dx_gate: Optional[torch.Tensor] = None) -> torch.Tensor:

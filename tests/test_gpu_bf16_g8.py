@@ -1,0 +1,90 @@
+"""GPU parity of the bf16 layer-to-layer form (st_conv3x3_fwd_bf16_g8, csrc/conv3x3_bf16.hip): activations handed
+from conv to conv in the channel-group layout G8 = bf16 [n][c/8][h][w][8].
+
+The bar is BIT-IDENTITY with the fp32-activation bf16 kernels (st_conv3x3_fwd_bf16 / st_conv3x3_pool_fwd_bf16, which
+tests/test_gpu_bf16.py pins to the oracle): a G8 value is the round-to-nearest-even those kernels apply to their
+input anyway, the chunk/tap accumulation order is the same, and rounding commutes with ReLU and max-pool.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from style_transfer_amd import ops as o
+    return o
+
+
+def _layer(ops, n, cin, cout, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    return x, ops.pack_conv3x3_weights(wt, False, "bf16"), b
+
+
+CASES = [
+    # n, cin, cout, h, w, up, relu, pool
+    (2, 64, 64, 40, 40, False, True, False),     # 64-ch tile (32 rows x 32)
+    (1, 64, 128, 33, 47, False, True, False),    # ragged both ways, 128-ch tile
+    (2, 128, 128, 37, 45, False, True, True),    # fused ceil-mode pool, odd sizes
+    (1, 64, 64, 64, 96, False, True, True),      # pool on the 64-ch tile
+    (1, 256, 256, 16, 16, True, True, False),    # fused x2 upsample
+    (1, 256, 128, 9, 13, True, True, False),     # upsample, ragged
+    (1, 512, 256, 8, 8, False, True, False),     # tile larger than the image
+    (1, 128, 64, 48, 32, False, False, False),   # no ReLU
+    (3, 16, 8, 20, 20, False, True, False),      # one chunk, one channel group
+    (1, 256, 512, 24, 40, False, True, False),   # four channel tiles per pixel tile
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,up,relu,pool", CASES)
+def test_g8_in_g8_out_is_bit_identical_to_fp32_activation_kernels(ops, n, cin, cout, h, w, up, relu, pool):
+    x, wp, b = _layer(ops, n, cin, cout, h, w, seed=cin + cout + h)
+    xg = ops.to_g8(x)
+    xq = ops.from_g8(xg)                      # fp32 tensor holding the bf16 values: the reference kernels' view
+    if pool:
+        ref = ops.conv3x3_pool(xq, wp, b, cout, "replicate", relu)
+    else:
+        ref = ops.conv3x3(xq, wp, b, cout, up, "replicate", relu)
+    got = ops.conv3x3_g8(xg, wp, b, cout, up, "replicate", relu, pool, y_g8=True)
+    assert ops.is_g8(got) and tuple(got.shape) == (n, cout // 8) + tuple(ref.shape[2:]) + (8,)
+    assert torch.equal(got, ops.to_g8(ref))
+    got32 = ops.conv3x3_g8(xg, wp, b, cout, up, "replicate", relu, pool, y_g8=False)
+    assert torch.equal(got32, ref)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,up,pool", [
+    (2, 3, 64, 37, 45, False, False),      # first encoder layer (channel tail) -> G8
+    (1, 512, 256, 16, 24, False, False),   # first decoder layer: fp32 AdaIN output -> G8
+    (1, 64, 64, 32, 64, False, True),
+    (1, 128, 128, 8, 8, True, False),
+])
+def test_fp32_in_g8_out(ops, n, cin, cout, h, w, up, pool):
+    x, wp, b = _layer(ops, n, cin, cout, h, w, seed=7 + cin)
+    ref = ops.conv3x3_pool(x, wp, b, cout, "replicate", True) if pool else ops.conv3x3(x, wp, b, cout, up, "replicate", True)
+    got = ops.conv3x3_g8(x, wp, b, cout, up, "replicate", True, pool, y_g8=True)
+    assert torch.equal(got, ops.to_g8(ref))
+
+
+def test_g8_in_three_channel_out(ops):
+    """Last decoder layer: G8 input, 3 output channels, fp32 NCHW result, no ReLU."""
+    x, wp, b = _layer(ops, 2, 64, 3, 40, 56, seed=5)
+    xg = ops.to_g8(x)
+    ref = ops.conv3x3(ops.from_g8(xg), wp, b, 3, False, "replicate", False)
+    got = ops.conv3x3_g8(xg, wp, b, 3, False, "replicate", False, False, y_g8=False)
+    assert torch.equal(got, ref)
+
+
+def test_g8_argument_checks(ops):
+    from style_transfer_amd._lib import StHipError
+    x, wp, b = _layer(ops, 1, 16, 12, 8, 8, seed=1)
+    with pytest.raises(StHipError):            # G8 output needs cout % 8 == 0
+        ops.conv3x3_g8(ops.to_g8(x), wp, b, 12, False, "replicate", True, False, y_g8=True)
+    x, wp, b = _layer(ops, 1, 16, 16, 8, 8, seed=1)
+    with pytest.raises(StHipError):            # G8 input: replicate padding only
+        ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, False, "zero", True, False, y_g8=True)
+    with pytest.raises(StHipError):            # pool and upsample exclude each other
+        ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, True, "replicate", True, True, y_g8=True)

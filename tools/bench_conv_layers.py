@@ -32,7 +32,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "dgrad_nogate", "wgrad"])
     ap.add_argument("--pad", default="replicate", choices=["replicate", "zero"])
-    ap.add_argument("--compute", default="f32", choices=["f32", "bf16", "bf16x3"])
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16", "bf16x3", "bf16g8"],
+                    help="bf16g8: bf16 kernels with the G8 bf16 activation layout on both sides where the layer allows")
     args = ap.parse_args()
     dev = torch.device("cuda")
     tot_t = tot_f = 0.0
@@ -41,11 +42,20 @@ def main():
         x = torch.randn(args.batch, cin, h, h, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         b = torch.randn(cout, device=dev)
-        wp = ops.pack_conv3x3_weights(w, compute=args.compute)
-        y = ops.conv3x3(x, wp, b, cout, upsample2x=up)
-        dy = torch.randn_like(y)
-        wpt = ops.pack_conv3x3_weights(w, transpose_flip=True, compute=args.compute)
-        if args.mode == "fwd":
+        if args.compute == "bf16g8":
+            assert args.mode == "fwd"
+            wp = ops.pack_conv3x3_weights(w, compute="bf16")
+            xin = ops.to_g8(x) if cin % 16 == 0 else x
+            yg = cout % 8 == 0
+            fn = lambda: ops.conv3x3_g8(xin, wp, b, cout, upsample2x=up, y_g8=yg)
+        else:
+            wp = ops.pack_conv3x3_weights(w, compute=args.compute)
+            y = ops.conv3x3(x, wp, b, cout, upsample2x=up)
+            dy = torch.randn_like(y)
+            wpt = ops.pack_conv3x3_weights(w, transpose_flip=True, compute=args.compute)
+        if args.compute == "bf16g8":
+            pass
+        elif args.mode == "fwd":
             fn = lambda: ops.conv3x3(x, wp, b, cout, upsample2x=up)
         elif args.mode == "dgrad":
             fn = lambda: ops.conv3x3_dgrad(dy, y, wpt, cin, up and args.pad == "replicate", args.pad)
