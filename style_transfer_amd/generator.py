@@ -106,6 +106,16 @@ class Encoder(nn.Module):
         seq = self.encode
         x = conv1x1_apply(x, seq[0].weight, seq[0].bias)
         frozen = not (torch.is_grad_enabled() and x.requires_grad)
+        if frozen and precision.get_compute_dtype() == "bf16":
+            # bf16 mode: the nine convs hand their activations to each other in the bf16 channel-group layout G8
+            # (ops.conv3x3_g8: half the HBM bytes, LDS-DMA staging; bit-identical to the fp32-activation kernels);
+            # fp32 NCHW at both ends
+            for idx in self.CONV3:
+                conv = seq[idx]
+                x = ops.conv3x3_g8(x, self._packed.get(idx, conv.weight, False, "bf16"), conv.bias.detach(),
+                                   int(conv.weight.shape[0]), upsample2x=False, pad_mode=ops.PAD_REPLICATE,
+                                   relu=True, pool=idx in self.POOL_AFTER, y_g8=idx != self.CONV3[-1])
+            return x
         for idx in self.CONV3:
             conv = seq[idx]
             if idx in self.POOL_AFTER and frozen:
@@ -166,6 +176,15 @@ class Decoder(nn.Module):
             assert not specs[-1][3], "the chain backward relies on the last conv having no ReLU"
             return DecoderChainFunction.apply(x.contiguous(), self._packed, tuple(specs), *params)
         up = False
+        if precision.get_compute_dtype() == "bf16":
+            x = x.contiguous()
+            for idx in self.CONV3:                # forward only, bf16 mode: G8 hand-overs as in Encoder.forward
+                conv = seq[idx]
+                x = ops.conv3x3_g8(x, self._packed.get(idx, conv.weight, False, "bf16"), conv.bias.detach(),
+                                   int(conv.weight.shape[0]), upsample2x=up, pad_mode=ops.PAD_REPLICATE,
+                                   relu=(idx != 28), pool=False, y_g8=(idx != 28))
+                up = idx in self.UP_AFTER
+            return x
         for idx in self.CONV3:
             conv = seq[idx]
             x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=up,

@@ -88,3 +88,38 @@ def test_g8_argument_checks(ops):
         ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, False, "zero", True, False, y_g8=True)
     with pytest.raises(StHipError):            # pool and upsample exclude each other
         ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, True, "replicate", True, True, y_g8=True)
+
+
+def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16():
+    """Encoder / Decoder forward in bf16 mode (G8 hand-overs between the nine convs of each) against the same
+    layers run one by one through the fp32-activation bf16 kernels; odd sizes so that the ceil-mode pools and
+    ragged tiles are on the path."""
+    from oracle import ref_ops as R
+    from style_transfer_amd import ops, precision
+    from style_transfer_amd.generator import Decoder, Encoder
+    enc = Encoder(weights=R.make_encoder_state(0)).cuda().eval()
+    dec = Decoder().cuda().eval()
+    dec.load_state_dict(R.make_decoder_state(1))
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 75, 91, generator=g).cuda()
+    with torch.no_grad(), precision.compute_dtype("bf16"):
+        feat = enc(x)
+        img = dec(feat)
+    # layer by layer, fp32 activations in HBM
+    seq = enc.encode
+    y = ops.conv1x1_3to3(x, seq[0].weight, seq[0].bias)
+    for idx in enc.CONV3:
+        wp = ops.pack_conv3x3_weights(seq[idx].weight, False, "bf16")
+        cout = int(seq[idx].weight.shape[0])
+        if idx in enc.POOL_AFTER:
+            y = ops.conv3x3_pool(y, wp, seq[idx].bias.detach(), cout, "replicate", True)
+        else:
+            y = ops.conv3x3(y, wp, seq[idx].bias.detach(), cout, False, "replicate", True)
+    assert feat.dtype == torch.float32 and torch.equal(feat, y)
+    seq = dec.decoder
+    up = False
+    for idx in dec.CONV3:
+        wp = ops.pack_conv3x3_weights(seq[idx].weight, False, "bf16")
+        y = ops.conv3x3(y, wp, seq[idx].bias.detach(), int(seq[idx].weight.shape[0]), up, "replicate", idx != 28)
+        up = idx in dec.UP_AFTER
+    assert img.dtype == torch.float32 and tuple(img.shape) == (2, 3, 80, 96) and torch.equal(img, y)
