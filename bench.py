@@ -300,8 +300,10 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
         return {"metric": "stylized 512x512 img/s (inference)", "value": round(value, 3), "unit": "img/s",
                 "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "dtype": compute,
-                "config": {"workload": f"inference batch {args.batch} at {args.side}x{args.side} per GPU, {what} / "
-                                       "fp32 NCHW activations", "batch_per_gpu": args.batch, "side": args.side},
+                "config": {"workload": f"inference batch {args.batch} at {args.side}x{args.side} per GPU, {what} / " +
+                                       ("fp32 NCHW activations" if x3 else
+                                        "fp32 NCHW at the encoder/AdaIN/decoder boundaries, bf16 channel-group (G8) "
+                                        "activations between the convs of each network"), "batch_per_gpu": args.batch, "side": args.side},
                 "model_tflops": round(value * per_img / 1e12, 2),
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": dom_name,

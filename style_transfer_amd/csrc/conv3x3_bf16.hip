@@ -408,7 +408,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #define ST_CHUNK_DMA(chunk_, MORE1_)                                                       \
   {                                                                                        \
     ST_READ_TAP(chunk_, 0, 0);                                                             \
-    if (MORE1_) { ST_ISSUE_W((chunk_) + 1); ST_ISSUE_XG((chunk_) + 1); }                   \
+    if (MORE1_) {                                                                          \
+      if (!(p.ablate & 4)) ST_ISSUE_W((chunk_) + 1);                                       \
+      if (!(p.ablate & 2)) ST_ISSUE_XG((chunk_) + 1);                                      \
+    }                                                                                      \
     asm volatile("" ::: "memory");                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                        \
@@ -730,7 +733,7 @@ int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS image exceeds the CU's 160 KB");
   p.tiles_x = st::cdiv(p.Wo, TW);
   p.tiles_y = st::cdiv(p.Ho, C::TH);
-  p.ablate = 0;
+  { const char* e = getenv("ST_BF16_ABLATE"); p.ablate = e ? atoi(e) : 0; }
   const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
   p.ctiles = st::cdiv(p.cout, C::BM);
   ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3_fwd_bf16_g8: too many tiles (%lld)", ptiles * p.ctiles);
