@@ -132,6 +132,13 @@ int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, const float* 
 int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y, int y_g8,
                            int n, int cin, int hin, int win, int cout, int upsample2x, int pad_mode, int relu,
                            int pool, st_stream_t stream);
+/* The same for the bf16x3 mode (weights from st_conv3x3_pack_weights_bf16x3): a "G8" activation is the hi/lo pair
+ * form bf16 [n][c/8][2][h][w][8] with part 0 = bf16(v) and part 1 = bf16(v - part 0) -- the split the kernels apply
+ * to an fp32 activation, done once by the producing layer; as many bytes as fp32, staged by LDS-DMA.  Bit-identical
+ * to chaining st_conv3x3_fwd_bf16x3 / st_conv3x3_pool_fwd_bf16x3. */
+int st_conv3x3_fwd_bf16x3_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y, int y_g8,
+                             int n, int cin, int hin, int win, int cout, int upsample2x, int pad_mode, int relu,
+                             int pool, st_stream_t stream);
 /* workspace: st_conv3x3_dgrad_workspace_bytes() (same as the fp32 entry point) */
 int st_conv3x3_dgrad_bf16(const float* dy, const float* y_gate, const void* w_packed_t, float* dx,
                           float* workspace, const float* dx_gate, int n, int cout, int h, int w, int cin,

@@ -88,7 +88,7 @@ struct Cfg {
   static constexpr int NW = (NWI + 7) / 8;        // ... per wave
   // 16-B units of the halo image: [part][half][position], rounded up to whole 1-KiB LDS-DMA pieces
   static constexpr int X_UNITS = (NPART * NITEM + 63) / 64 * 64;
-  static constexpr int NXI = (NITEM + 63) / 64;   // XG: 1-KiB LDS-DMA wave instructions per halo image
+  static constexpr int NXI = (NPART * NITEM + 63) / 64;   // XG: 1-KiB LDS-DMA wave instructions per halo image
   static constexpr int NXW = (NXI + 7) / 8;       // ... per wave
   static constexpr size_t LDS_BYTES = size_t(2 * W_UNITS + 2 * X_UNITS) * 16;   // both double-buffered
 };
@@ -108,14 +108,15 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
 // group is the 16-B unit of the LDS halo image, so an XG kernel stages its input by LDS-DMA like the weights (no
 // registers, no conversion, half the bytes of the fp32 form); a YG kernel rounds its result to bf16 (the same
 // round-to-nearest-even the next layer's staging would apply to an fp32 result: the chain is bit-identical to the
-// fp32-activation form) and writes 16 B per pixel and channel group.
+// fp32-activation form) and writes 16 B per pixel and channel group.  With SPLIT (bf16x3) the layout is the hi/lo
+// pair form bf16 [n][c/8][2][h][w][8] (part 0 = bf16(v), part 1 = bf16(v - hi): the same split the staging of an
+// fp32 activation performs, done once by the producer): as many bytes as fp32, but both images arrive by LDS-DMA.
 template <int MT, int NT, int WM, int WP, bool GATE, bool TAIL, bool SPLIT, bool PIPE, bool XG = false,
           bool YG = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p) {
   using C = Cfg<MT, NT, WM, WP, SPLIT>;
   static_assert(WM * WP == 8, "eight waves per block");
-  static_assert(!XG || (!GATE && !TAIL && !SPLIT), "G8 input: plain forward form only");
-  static_assert(!YG || !SPLIT, "G8 output: bf16 mode only");
+  static_assert(!XG || (!GATE && !TAIL), "G8 input: plain forward form only");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   u32x4* Ws = smem16;                     // 2 x [part][tap][half][BM]   (filled by LDS-DMA)
   u32x4* Xs = smem16 + 2 * C::W_UNITS;    // 2 x [part][half][position]
@@ -158,16 +159,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // XG: wave w copies 1-KiB pieces u = i*8 + w of the halo image; lane -> 16-B unit (half, position) u*64 + lane,
   // source = the (clamped, optionally upsampled) pixel of channel group 2*chunk + half
   unsigned xoff[XG ? C::NXW : 1];
-  const u32x4* xg = reinterpret_cast<const u32x4*>(p.x) + size_t(b) * (p.cin / 8) * plane_src;
+  const u32x4* xg = reinterpret_cast<const u32x4*>(p.x) + size_t(b) * (p.cin / 8) * C::NPART * plane_src;
   if constexpr (XG) {
 #pragma unroll
     for (int i = 0; i < C::NXW; ++i) {
-      const int idx = min((i * 8 + wave) * 64 + lane, C::NITEM - 1);
+      int idx = min((i * 8 + wave) * 64 + lane, C::NPART * C::NITEM - 1);
+      const int part = idx / C::NITEM;
+      idx -= part * C::NITEM;
       const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;
       const int r = pidx / HC, cc = pidx - r * HC;
       int cy = min(max(y0 + r - 1, 0), p.H - 1), cx = min(max(x0 + cc - 1, 0), p.W - 1);
       if (p.up) { cy >>= 1; cx >>= 1; }
-      xoff[i] = unsigned(half) * unsigned(plane_src) + unsigned(cy * p.ws + cx);
+      xoff[i] = unsigned(half * C::NPART + part) * unsigned(plane_src) + unsigned(cy * p.ws + cx);
     }
   }
 #pragma unroll
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // XG: halo image of chunk_ -> X buffer (chunk_ & 1) by LDS-DMA
 #define ST_ISSUE_XG(chunk_)                                                                \
   {                                                                                        \
-    const u32x4* xsrc = xg + size_t(chunk_) * 2 * plane_src;                               \
+    const u32x4* xsrc = xg + size_t(chunk_) * (2 * C::NPART) * plane_src;                  \
     u32x4* xdst = Xs + ((chunk_) & 1) * C::X_UNITS;                                        \
     _Pragma("unroll") for (int i = 0; i < C::NXW; ++i) {                                   \
       const int u = i * 8 + wave;                                                          \
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   }
   ST_BARRIER_DRAIN();
   if constexpr (XG) {
-    bf16x8 pa[2][MT], pb[2][NT], pal[1][MT], pbl[1][NT];
+    bf16x8 pa[2][MT], pb[2][NT], pal[SPLIT ? 2 : 1][MT], pbl[SPLIT ? 2 : 1][NT];
     int chunk = 0;
     for (; chunk + 1 < nch; ++chunk) ST_CHUNK_DMA(chunk, true);
     ST_CHUNK_DMA(chunk, false);
@@ -495,14 +498,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // cover one 128-B row segment, a wave instruction writes 8 channel rows.
   if constexpr (YG) {
     // G8 bf16 output: a wave turns each 32 ch x 32 px accumulator tile into [32 px][4 groups][8 ch] bf16 through a
-    // private 2 KB LDS patch (lanes l and l+32 hold the two halves of a pixel's 8-channel group) and stores 16 B
-    // per lane: 32 lanes cover 512 contiguous bytes of one channel group's row.
-    unsigned* patch = reinterpret_cast<unsigned*>(smem16 + wave * 128);
+    // private 2 KB LDS patch per image (lanes l and l+32 hold the two halves of a pixel's 8-channel group) and
+    // stores 16 B per lane: 32 lanes cover 512 contiguous bytes of one channel group's row.  SPLIT: a second
+    // patch / store for the lo image.
+    constexpr int NPT = C::NPART;
+    unsigned* patch = reinterpret_cast<unsigned*>(smem16 + wave * (128 * NPT));
     const u32x4* patch16 = reinterpret_cast<const u32x4*>(patch);
     u32x4* yg = reinterpret_cast<u32x4*>(p.y);
     const int cgroups = p.cout >> 3;
     const bool pool = p.pool != 0;
     const int Hy = pool ? (p.Ho + 1) >> 1 : p.Ho, Wy = pool ? (p.Wo + 1) >> 1 : p.Wo;
+    const size_t plane_y = size_t(Hy) * Wy;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int cbase = m0 + wm * (MT * 32) + mt * 32;
@@ -512,70 +518,71 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
         bv[r] = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
       }
+      // one output row (POOL_ = false) or one pooled row from the row pair (nt_, nt_ + 1) (POOL_ = true; fused
+      // MaxPool2d((2,2),(2,2),ceil_mode=True): rounding is monotonic, so max-then-round equals the pool of the
+      // rounded activation; even lanes hold the 16 pooled pixels)
+#define ST_G8_ROW(POOL_, nt_)                                                                         \
+  {                                                                                                   \
+    const int yy = y0 + wp * NT + (nt_);                                                              \
+    const int slot = (POOL_) ? (li >> 1) : li;                                                        \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+      bf16x4 h, l;                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+        float v = acc[mt][nt_][q * 4 + j];                                                            \
+        if (POOL_) {                                                                                  \
+          if (yy + 1 < p.Ho) v = fmaxf(v, acc[mt][(nt_) + 1 < NT ? (nt_) + 1 : (nt_)][q * 4 + j]);    \
+          const float vn = __shfl_xor(v, 1, 64);                                                      \
+          if (x0 + li + 1 < p.Wo) v = fmaxf(v, vn);                                                   \
+        }                                                                                             \
+        v += bv[q * 4 + j];                                                                           \
+        if (p.relu) v = fmaxf(v, 0.f);                                                                \
+        h[j] = (__bf16)v;                                                                             \
+        if (SPLIT) l[j] = (__bf16)(v - float(h[j]));                                                  \
+      }                                                                                               \
+      if (!(POOL_) || !(li & 1)) {                                                                    \
+        const u32x2 hv = __builtin_bit_cast(u32x2, h);                                                \
+        patch[(slot * 4 + q) * 4 + lh * 2 + 0] = hv[0];                                               \
+        patch[(slot * 4 + q) * 4 + lh * 2 + 1] = hv[1];                                               \
+        if (SPLIT) {                                                                                  \
+          const u32x2 lv = __builtin_bit_cast(u32x2, l);                                              \
+          patch[512 + (slot * 4 + q) * 4 + lh * 2 + 0] = lv[0];                                       \
+          patch[512 + (slot * 4 + q) * 4 + lh * 2 + 1] = lv[1];                                       \
+        }                                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+    asm volatile("" ::: "memory");                                                                    \
+    if (!(POOL_)) {                                                                                   \
+      _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                 \
+        const int q = k * 2 + lh;                                                                     \
+        const int cg = (cbase >> 3) + q, xs = x0 + li;                                                \
+        const bool ok = cg < cgroups && yy < p.Ho && xs < p.Wo;                                       \
+        const size_t o = (size_t(b) * cgroups + cg) * NPT * plane_y + size_t(yy) * Wy + xs;           \
+        _Pragma("unroll") for (int part = 0; part < NPT; ++part) {                                    \
+          const u32x4 v = patch16[part * 128 + li * 4 + q];                                           \
+          if (ok) yg[o + part * plane_y] = v;                                                         \
+        }                                                                                             \
+      }                                                                                               \
+    } else {                                                                                          \
+      const int q = lane >> 4, px = lane & 15;                                                        \
+      const int cg = (cbase >> 3) + q;                                                                \
+      const bool ok = cg < cgroups && yy < p.Ho && x0 + 2 * px < p.Wo;                                \
+      const size_t o =                                                                                \
+          (size_t(b) * cgroups + cg) * NPT * plane_y + size_t(yy >> 1) * Wy + (x0 >> 1) + px;         \
+      _Pragma("unroll") for (int part = 0; part < NPT; ++part) {                                      \
+        const u32x4 v = patch16[part * 128 + px * 4 + q];                                             \
+        if (ok) yg[o + part * plane_y] = v;                                                           \
+      }                                                                                               \
+    }                                                                                                 \
+    asm volatile("" ::: "memory");                                                                    \
+  }
       if (!pool) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int yy = y0 + wp * NT + nt;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            bf16x4 h;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float v = acc[mt][nt][q * 4 + j] + bv[q * 4 + j];
-              if (p.relu) v = fmaxf(v, 0.f);
-              h[j] = (__bf16)v;
-            }
-            const u32x2 hv = __builtin_bit_cast(u32x2, h);
-            patch[(li * 4 + q) * 4 + lh * 2 + 0] = hv[0];
-            patch[(li * 4 + q) * 4 + lh * 2 + 1] = hv[1];
-          }
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int q = k * 2 + lh;
-            const u32x4 v = patch16[li * 4 + q];
-            const int cg = (cbase >> 3) + q, xs = x0 + li;
-            if (cg < cgroups && yy < p.Ho && xs < p.Wo)
-              yg[((size_t(b) * cgroups + cg) * Hy + yy) * Wy + xs] = v;
-          }
-          asm volatile("" ::: "memory");
-        }
+        for (int nt = 0; nt < NT; ++nt) ST_G8_ROW(false, nt)
       } else {
-        // fused MaxPool2d((2,2),(2,2),ceil_mode=True): rounding is monotonic, so max-then-round equals the
-        // pool of the rounded activation
 #pragma unroll
-        for (int nt = 0; nt + 1 < NT; nt += 2) {
-          const int yy = y0 + wp * NT + nt;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            bf16x4 h;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float v = acc[mt][nt][q * 4 + j];
-              if (yy + 1 < p.Ho) v = fmaxf(v, acc[mt][nt + 1][q * 4 + j]);
-              const float vn = __shfl_xor(v, 1, 64);
-              if (x0 + li + 1 < p.Wo) v = fmaxf(v, vn);
-              v += bv[q * 4 + j];
-              if (p.relu) v = fmaxf(v, 0.f);
-              h[j] = (__bf16)v;
-            }
-            const u32x2 hv = __builtin_bit_cast(u32x2, h);
-            if (!(li & 1)) {
-              patch[((li >> 1) * 4 + q) * 4 + lh * 2 + 0] = hv[0];
-              patch[((li >> 1) * 4 + q) * 4 + lh * 2 + 1] = hv[1];
-            }
-          }
-          asm volatile("" ::: "memory");
-          {
-            const int q = lane >> 4, px = lane & 15;
-            const u32x4 v = patch16[px * 4 + q];
-            const int cg = (cbase >> 3) + q;
-            if (cg < cgroups && yy < p.Ho && x0 + 2 * px < p.Wo)
-              yg[((size_t(b) * cgroups + cg) * Hy + (yy >> 1)) * Wy + (x0 >> 1) + px] = v;
-          }
-          asm volatile("" ::: "memory");
-        }
+        for (int nt = 0; nt + 1 < NT; nt += 2) ST_G8_ROW(true, nt)
       }
+#undef ST_G8_ROW
     }
   } else if (p.pool) {
     // fused MaxPool2d((2,2),(2,2),ceil_mode=True) (generator.py:53,60,73), as in csrc/conv3x3.hip
@@ -727,9 +734,9 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
 }
 
 // G8 forms (st_conv3x3_fwd_bf16_g8): xg / yg select the activation layout on either side
-template <int MT, int NT, int WM, int WP>
+template <int MT, int NT, int WM, int WP, bool SPLIT = false>
 int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
-  using C = Cfg<MT, NT, WM, WP, false>;
+  using C = Cfg<MT, NT, WM, WP, SPLIT>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS image exceeds the CU's 160 KB");
   p.tiles_x = st::cdiv(p.Wo, TW);
   p.tiles_y = st::cdiv(p.Ho, C::TH);
@@ -741,16 +748,16 @@ int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
   p.vec_store = (p.ldo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
   dim3 grid((unsigned)(ptiles * p.ctiles));
   if (xg && yg)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, false, true, true>), grid,
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), grid,
                        dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else if (xg)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, false, true, false>), grid,
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, false>), grid,
                        dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else if (p.cin % KC != 0)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, true, false, false, false, true>), grid,
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, true, SPLIT, false, false, true>), grid,
                        dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, true, false, true>), grid,
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, true, false, true>), grid,
                        dim3(NTHREADS), C::LDS_BYTES, stream, p);
   return st::check_launch("st_conv3x3_fwd_bf16_g8");
 }
@@ -850,9 +857,9 @@ extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, co
   return conv3x3_fwd_bf16_impl(x, w_packed, bias, ypool, n, cin, hin, win, cout, 0, pad_mode, relu, 1, stream);
 }
 
-extern "C" int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
-                                      int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
-                                      int pad_mode, int relu, int pool, st_stream_t stream) {
+static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
+                               int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
+                               int pad_mode, int relu, int pool, st_stream_t stream, bool split) {
   ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16_g8: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
              "st_conv3x3_fwd_bf16_g8: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
@@ -861,7 +868,7 @@ extern "C" int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_pac
   ST_REQUIRE(!(pool && upsample2x), "st_conv3x3_fwd_bf16_g8: pool and upsample2x exclude each other");
   if (!x_g8 && !y_g8)
     return conv3x3_fwd_bf16_impl((const float*)x, w_packed, bias, (float*)y, n, cin, hin, win, cout, upsample2x,
-                                 pad_mode, relu, pool, stream);
+                                 pad_mode, relu, pool, stream, split);
   ST_REQUIRE(!x_g8 || (cin % KC == 0 && pad_mode == ST_PAD_REPLICATE),
              "st_conv3x3_fwd_bf16_g8: a G8 input needs cin %% 16 == 0 (got %d) and replicate padding", cin);
   ST_REQUIRE(!x_g8 || reinterpret_cast<uintptr_t>(x) % 16 == 0, "st_conv3x3_fwd_bf16_g8: x must be 16-byte aligned");
@@ -879,9 +886,24 @@ extern "C" int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_pac
   p.pad_zero = pad_mode == ST_PAD_ZERO;
   p.relu = relu ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
+  if (split) return launch_conv_g8<1, 4, 2, 4, true>(p, x_g8 != 0, y_g8 != 0, s);   // 64 ch x (16 rows x 32)
   if (cout > 64) return launch_conv_g8<2, 4, 2, 4>(p, x_g8 != 0, y_g8 != 0, s);   // 128 ch x (16 rows x 32)
   if (cout > 32) return launch_conv_g8<2, 4, 1, 8>(p, x_g8 != 0, y_g8 != 0, s);   //  64 ch x (32 rows x 32)
   return launch_conv_g8<1, 4, 1, 8>(p, x_g8 != 0, y_g8 != 0, s);                  //  32 ch x (32 rows x 32)
+}
+
+extern "C" int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
+                                      int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
+                                      int pad_mode, int relu, int pool, st_stream_t stream) {
+  return conv3x3_fwd_g8_impl(x, x_g8, w_packed, bias, y, y_g8, n, cin, hin, win, cout, upsample2x, pad_mode, relu,
+                             pool, stream, false);
+}
+
+extern "C" int st_conv3x3_fwd_bf16x3_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
+                                        int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
+                                        int pad_mode, int relu, int pool, st_stream_t stream) {
+  return conv3x3_fwd_g8_impl(x, x_g8, w_packed, bias, y, y_g8, n, cin, hin, win, cout, upsample2x, pad_mode, relu,
+                             pool, stream, true);
 }
 
 extern "C" int st_conv3x3_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y,

@@ -58,6 +58,32 @@ class _PackedWeightCache:
         self._c.clear()
 
 
+def _g8_chain(x, seq, idxs, packed, compute, pool_after=(), up_after=(), relu_last=True):
+    """Forward-only [pad, conv3x3, ReLU] chain in a bf16 compute mode: the convs hand their activations to each
+    other in the bf16 channel-group layout G8 (bf16x3: the hi/lo pair form) -- ops.conv3x3_g8: LDS-DMA staging, half
+    the HBM bytes in bf16 mode, bit-identical to the fp32-activation kernels.  fp32 NCHW at both ends.  In bf16x3
+    mode the 3-channel layers stay on the exact fp32 vector-ALU kernels (see _PackedWeightCache.get)."""
+    def small(idx):
+        return compute == "bf16x3" and 3 in (int(seq[idx].weight.shape[0]), int(seq[idx].weight.shape[1]))
+
+    up = False
+    for k, idx in enumerate(idxs):
+        conv = seq[idx]
+        cout = int(conv.weight.shape[0])
+        last = k == len(idxs) - 1
+        relu = relu_last or not last
+        if small(idx):
+            assert idx not in pool_after
+            x = ops.conv3x3(x, packed.get(idx, conv.weight, False, "f32"), conv.bias.detach(), cout, up,
+                            ops.PAD_REPLICATE, relu)
+        else:
+            x = ops.conv3x3_g8(x, packed.get(idx, conv.weight, False, compute), conv.bias.detach(), cout,
+                               upsample2x=up, pad_mode=ops.PAD_REPLICATE, relu=relu, pool=idx in pool_after,
+                               y_g8=not last and not small(idxs[k + 1]))
+        up = idx in up_after     # the next conv reads this output through a x2 nearest upsample
+    return x
+
+
 def _load_state(path_or_sd: Union[str, dict]) -> dict:
     if isinstance(path_or_sd, dict):
         return path_or_sd
@@ -106,16 +132,9 @@ class Encoder(nn.Module):
         seq = self.encode
         x = conv1x1_apply(x, seq[0].weight, seq[0].bias)
         frozen = not (torch.is_grad_enabled() and x.requires_grad)
-        if frozen and precision.get_compute_dtype() == "bf16":
-            # bf16 mode: the nine convs hand their activations to each other in the bf16 channel-group layout G8
-            # (ops.conv3x3_g8: half the HBM bytes, LDS-DMA staging; bit-identical to the fp32-activation kernels);
-            # fp32 NCHW at both ends
-            for idx in self.CONV3:
-                conv = seq[idx]
-                x = ops.conv3x3_g8(x, self._packed.get(idx, conv.weight, False, "bf16"), conv.bias.detach(),
-                                   int(conv.weight.shape[0]), upsample2x=False, pad_mode=ops.PAD_REPLICATE,
-                                   relu=True, pool=idx in self.POOL_AFTER, y_g8=idx != self.CONV3[-1])
-            return x
+        if frozen and precision.get_compute_dtype() in ("bf16", "bf16x3"):
+            return _g8_chain(x, seq, self.CONV3, self._packed, precision.get_compute_dtype(),
+                             pool_after=self.POOL_AFTER)
         for idx in self.CONV3:
             conv = seq[idx]
             if idx in self.POOL_AFTER and frozen:
@@ -176,15 +195,9 @@ class Decoder(nn.Module):
             assert not specs[-1][3], "the chain backward relies on the last conv having no ReLU"
             return DecoderChainFunction.apply(x.contiguous(), self._packed, tuple(specs), *params)
         up = False
-        if precision.get_compute_dtype() == "bf16":
-            x = x.contiguous()
-            for idx in self.CONV3:                # forward only, bf16 mode: G8 hand-overs as in Encoder.forward
-                conv = seq[idx]
-                x = ops.conv3x3_g8(x, self._packed.get(idx, conv.weight, False, "bf16"), conv.bias.detach(),
-                                   int(conv.weight.shape[0]), upsample2x=up, pad_mode=ops.PAD_REPLICATE,
-                                   relu=(idx != 28), pool=False, y_g8=(idx != 28))
-                up = idx in self.UP_AFTER
-            return x
+        if precision.get_compute_dtype() in ("bf16", "bf16x3"):
+            return _g8_chain(x.contiguous(), seq, self.CONV3, self._packed, precision.get_compute_dtype(),
+                             up_after=self.UP_AFTER, relu_last=False)
         for idx in self.CONV3:
             conv = seq[idx]
             x = conv3x3_apply(x, conv.weight, conv.bias, self._packed, idx, upsample2x=up,

@@ -182,6 +182,28 @@ def is_g8(x: torch.Tensor) -> bool:
     return x.dim() == 5 and x.dtype == torch.bfloat16 and x.shape[-1] == 8
 
 
+def to_g8_pair(x: torch.Tensor) -> torch.Tensor:
+    """fp32 NCHW -> the bf16x3 hi/lo pair layout bf16 [n, c/8, 2, h, w, 8]: part 0 = bf16(v), part 1 = bf16(v - hi)."""
+    n, c, h, w = x.shape
+    assert c % 8 == 0, f"G8 needs c % 8 == 0, got {c}"
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    pair = torch.stack([hi, lo], dim=0).view(2, n, c // 8, 8, h, w)
+    return pair.permute(1, 2, 0, 4, 5, 3).contiguous()
+
+
+def from_g8_pair(g: torch.Tensor) -> torch.Tensor:
+    """bf16x3 pair layout -> fp32 NCHW (hi + lo, exact in fp32)."""
+    n, cg, two, h, w, e = g.shape
+    assert two == 2 and e == 8 and g.dtype == torch.bfloat16
+    v = g[:, :, 0].float() + g[:, :, 1].float()
+    return v.permute(0, 1, 4, 2, 3).reshape(n, cg * 8, h, w).contiguous()
+
+
+def is_g8_pair(x: torch.Tensor) -> bool:
+    return x.dim() == 6 and x.dtype == torch.bfloat16 and x.shape[-1] == 8 and x.shape[2] == 2
+
+
 def conv3x3_g8(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                upsample2x: bool = False, pad_mode="replicate", relu: bool = True, pool: bool = False,
                y_g8: bool = True) -> torch.Tensor:
@@ -189,27 +211,30 @@ def conv3x3_g8(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     ``x`` is fp32 NCHW or a G8 tensor (is_g8); the result is G8 when ``y_g8`` else fp32 NCHW.  Bit-identical
     to conv3x3 / conv3x3_pool with bf16-packed weights on the same values.  Forward only."""
     lib = _lib.load()
-    x_g8 = is_g8(x)
+    x_g8 = is_g8(x) or is_g8_pair(x)
     if x_g8:
-        n, cg, h, w, _ = (int(v) for v in x.shape)
+        n, cg, h, w = int(x.shape[0]), int(x.shape[1]), int(x.shape[-3]), int(x.shape[-2])
         cin = cg * 8
     else:
         assert x.dim() == 4 and x.dtype == torch.float32, "conv3x3_g8 expects fp32 NCHW or a G8 tensor"
         n, cin, h, w = (int(v) for v in x.shape)
     assert x.is_contiguous()
     fam = conv_family(w_packed, cout, cin)
-    assert fam == "bf16", "conv3x3_g8 needs bf16-packed weights"
+    assert fam in ("bf16", "bf16x3"), "conv3x3_g8 needs bf16- or bf16x3-packed weights"
+    pair = fam == "bf16x3"
+    assert not x_g8 or is_g8_pair(x) == pair, "G8 input form does not match the packed weights (bf16 vs bf16x3)"
     s = 2 if upsample2x else 1
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h * s, w * s)
     if y_g8:
-        y = torch.empty((n, cout // 8, ho, wo, 8), dtype=torch.bfloat16, device=x.device)
+        shape = (n, cout // 8, 2, ho, wo, 8) if pair else (n, cout // 8, ho, wo, 8)
+        y = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
     else:
         y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
     ev = None
     if KERNEL_TIMER.enabled:
-        ev = KERNEL_TIMER.record(conv_kernel_name(cout, "bf16"), 2.0 * n * h * s * w * s * cin * cout * 9,
+        ev = KERNEL_TIMER.record(conv_kernel_name(cout, fam), 2.0 * n * h * s * w * s * cin * cout * 9,
                                  float(x.numel() * x.element_size() + y.numel() * y.element_size()))
-    _lib.check(lib.st_conv3x3_fwd_bf16_g8(
+    _lib.check(getattr(lib, "st_conv3x3_fwd" + _SUFFIX[fam] + "_g8")(
         _lib.dev_ptr(x, "x", x.dtype), int(x_g8), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
         _lib.dev_ptr(bias, "bias") if bias is not None else None, _lib.dev_ptr(y, "y", y.dtype), int(y_g8),
         n, cin, h, w, cout, int(upsample2x), _pad_code(pad_mode), int(relu), int(pool), _lib.stream_ptr()),

@@ -90,10 +90,11 @@ def test_g8_argument_checks(ops):
         ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, True, "replicate", True, True, y_g8=True)
 
 
-def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16():
-    """Encoder / Decoder forward in bf16 mode (G8 hand-overs between the nine convs of each) against the same
-    layers run one by one through the fp32-activation bf16 kernels; odd sizes so that the ceil-mode pools and
-    ragged tiles are on the path."""
+@pytest.mark.parametrize("compute", ["bf16", "bf16x3"])
+def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16(compute):
+    """Encoder / Decoder forward in bf16 / bf16x3 mode (G8 hand-overs between the nine convs of each) against the
+    same layers run one by one through the fp32-activation kernels of that mode; odd sizes so that the ceil-mode
+    pools and ragged tiles are on the path."""
     from oracle import ref_ops as R
     from style_transfer_amd import ops, precision
     from style_transfer_amd.generator import Decoder, Encoder
@@ -102,14 +103,18 @@ def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16():
     dec.load_state_dict(R.make_decoder_state(1))
     g = torch.Generator().manual_seed(3)
     x = torch.rand(2, 3, 75, 91, generator=g).cuda()
-    with torch.no_grad(), precision.compute_dtype("bf16"):
+    with torch.no_grad(), precision.compute_dtype(compute):
         feat = enc(x)
         img = dec(feat)
+
+    def pack(w):
+        small = compute == "bf16x3" and 3 in (int(w.shape[0]), int(w.shape[1]))   # exact fp32 vector-ALU kernels
+        return ops.pack_conv3x3_weights(w, False, "f32" if small else compute)
     # layer by layer, fp32 activations in HBM
     seq = enc.encode
     y = ops.conv1x1_3to3(x, seq[0].weight, seq[0].bias)
     for idx in enc.CONV3:
-        wp = ops.pack_conv3x3_weights(seq[idx].weight, False, "bf16")
+        wp = pack(seq[idx].weight)
         cout = int(seq[idx].weight.shape[0])
         if idx in enc.POOL_AFTER:
             y = ops.conv3x3_pool(y, wp, seq[idx].bias.detach(), cout, "replicate", True)
@@ -119,7 +124,28 @@ def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16():
     seq = dec.decoder
     up = False
     for idx in dec.CONV3:
-        wp = ops.pack_conv3x3_weights(seq[idx].weight, False, "bf16")
+        wp = pack(seq[idx].weight)
         y = ops.conv3x3(y, wp, seq[idx].bias.detach(), int(seq[idx].weight.shape[0]), up, "replicate", idx != 28)
         up = idx in dec.UP_AFTER
     assert img.dtype == torch.float32 and tuple(img.shape) == (2, 3, 80, 96) and torch.equal(img, y)
+
+
+# ---- bf16x3: hi/lo pair layout -------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,cin,cout,h,w,up,relu,pool", CASES)
+def test_g8_pair_is_bit_identical_to_fp32_activation_bf16x3_kernels(ops, n, cin, cout, h, w, up, relu, pool):
+    """bf16x3: the pair layout holds exactly the (hi, lo) split the fp32-activation kernel makes of its input, and a
+    pair output is the split of the fp32 result: both directions compare bit for bit."""
+    g = torch.Generator().manual_seed(cin * 3 + cout + w)
+    x = torch.randn(n, cin, h, w, generator=g).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    wp = ops.pack_conv3x3_weights(wt, False, "bf16x3")
+    ref = ops.conv3x3_pool(x, wp, b, cout, "replicate", relu) if pool else ops.conv3x3(x, wp, b, cout, up, "replicate", relu)
+    xg = ops.to_g8_pair(x)
+    assert torch.equal(ops.from_g8_pair(xg), x) or float((ops.from_g8_pair(xg) - x).abs().max()) < 1e-4
+    got32 = ops.conv3x3_g8(xg, wp, b, cout, up, "replicate", relu, pool, y_g8=False)
+    assert torch.equal(got32, ref)
+    got = ops.conv3x3_g8(xg, wp, b, cout, up, "replicate", relu, pool, y_g8=True)
+    assert ops.is_g8_pair(got) and torch.equal(got, ops.to_g8_pair(ref))
+    got_b = ops.conv3x3_g8(x, wp, b, cout, up, "replicate", relu, pool, y_g8=True)     # fp32 in -> pair out
+    assert torch.equal(got_b, got)
