@@ -70,6 +70,7 @@ struct ConvParams {
   int cout_pad, nchunks;
   int up, pad_zero, relu;
   int tiles_x, tiles_y, ctiles, xcd_swizzle;
+  int ntiles;              // PERSIST kernels: total (pixel tile, channel tile) pairs, walked with stride gridDim.x
   int vec_store;           // ldo % 4 == 0 and y 16-B aligned: 16-B-per-lane epilogue stores
   int ablate;              // debug only (ST_BF16_ABLATE): 1 skip MFMA, 2 skip X staging, 4 skip W DMA
 };
@@ -129,24 +130,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // Block -> (pixel tile, channel tile).  Blocks are dealt round-robin over the 8 XCDs (each with
   // its own L2), so ids that differ by 8 share an XCD: the channel tiles of one pixel tile get
   // consecutive slots on ONE XCD and the 2..4 reads of the same activation tile hit its L2.
-  int bt, ct;
-  {
-    const int id = blockIdx.x;
-    if (p.xcd_swizzle) {
-      const int k = id >> 3;
-      ct = k % p.ctiles;
-      bt = (k / p.ctiles) * 8 + (id & 7);
-    } else {
-      ct = id % p.ctiles;
-      bt = id / p.ctiles;
-    }
+  // PERSIST (G8 in and out, bf16): the grid is one block per CU and a block walks tiles id, id + gridDim.x, ...;
+  // the LDS-DMA of the next tile's first chunk is issued before the epilogue of the current one, so neither the
+  // first-chunk latency nor the block launch sits between two tiles' MFMA loops.
+  constexpr bool PERSIST = XG && YG && !SPLIT;
+  int b, m0, x0, y0;
+#define ST_DECODE_TILE(id_, b_, m0_, x0_, y0_)                                             \
+  {                                                                                        \
+    int bt_, ct_;                                                                          \
+    if (p.xcd_swizzle) {                                                                   \
+      const int k_ = (id_) >> 3;                                                           \
+      ct_ = k_ % p.ctiles;                                                                 \
+      bt_ = (k_ / p.ctiles) * 8 + ((id_) & 7);                                             \
+    } else {                                                                               \
+      ct_ = (id_) % p.ctiles;                                                              \
+      bt_ = (id_) / p.ctiles;                                                              \
+    }                                                                                      \
+    const int tx_ = bt_ % p.tiles_x;                                                       \
+    bt_ /= p.tiles_x;                                                                      \
+    const int ty_ = bt_ % p.tiles_y;                                                       \
+    b_ = bt_ / p.tiles_y;                                                                  \
+    m0_ = ct_ * C::BM;                                                                     \
+    x0_ = tx_ * TW;                                                                        \
+    y0_ = ty_ * C::TH;                                                                     \
   }
-  const int tx = bt % p.tiles_x;
-  bt /= p.tiles_x;
-  const int ty = bt % p.tiles_y;
-  const int b = bt / p.tiles_y;
-  const int m0 = ct * C::BM;
-  const int x0 = tx * TW, y0 = ty * C::TH;
+  int tile = blockIdx.x;
+  ST_DECODE_TILE(tile, b, m0, x0, y0);
 
   const size_t plane_src = size_t(p.hs) * p.ws;
   const float* xb = p.x + size_t(b) * p.cin * plane_src;
@@ -159,20 +168,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // XG: wave w copies 1-KiB pieces u = i*8 + w of the halo image; lane -> 16-B unit (half, position) u*64 + lane,
   // source = the (clamped, optionally upsampled) pixel of channel group 2*chunk + half
   unsigned xoff[XG ? C::NXW : 1];
-  const u32x4* xg = reinterpret_cast<const u32x4*>(p.x) + size_t(b) * (p.cin / 8) * C::NPART * plane_src;
-  if constexpr (XG) {
-#pragma unroll
-    for (int i = 0; i < C::NXW; ++i) {
-      int idx = min((i * 8 + wave) * 64 + lane, C::NPART * C::NITEM - 1);
-      const int part = idx / C::NITEM;
-      idx -= part * C::NITEM;
-      const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;
-      const int r = pidx / HC, cc = pidx - r * HC;
-      int cy = min(max(y0 + r - 1, 0), p.H - 1), cx = min(max(x0 + cc - 1, 0), p.W - 1);
-      if (p.up) { cy >>= 1; cx >>= 1; }
-      xoff[i] = unsigned(half * C::NPART + part) * unsigned(plane_src) + unsigned(cy * p.ws + cx);
-    }
+  const u32x4* xg = nullptr;
+#define ST_XOFF(b_, x0_, y0_, xg_, xoff_)                                                  \
+  {                                                                                        \
+    xg_ = reinterpret_cast<const u32x4*>(p.x) + size_t(b_) * (p.cin / 8) * C::NPART * plane_src; \
+    _Pragma("unroll") for (int i = 0; i < C::NXW; ++i) {                                   \
+      int idx = min((i * 8 + wave) * 64 + lane, C::NPART * C::NITEM - 1);                  \
+      const int part = idx / C::NITEM;                                                     \
+      idx -= part * C::NITEM;                                                              \
+      const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;                       \
+      const int r = pidx / HC, cc = pidx - r * HC;                                         \
+      int cy = min(max((y0_) + r - 1, 0), p.H - 1), cx = min(max((x0_) + cc - 1, 0), p.W - 1); \
+      if (p.up) { cy >>= 1; cx >>= 1; }                                                    \
+      xoff_[i] = unsigned(half * C::NPART + part) * unsigned(plane_src) + unsigned(cy * p.ws + cx); \
+    }                                                                                      \
   }
+  if constexpr (XG) ST_XOFF(b, x0, y0, xg, xoff);
 #pragma unroll
   for (int i = 0; i < (XG ? 0 : C::NP); ++i) {
     const int idx = min(tid + i * NTHREADS, C::NITEM - 1);
@@ -202,9 +213,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 
   // ---- staging macros ----------------------------------------------------------------------
   // weights of chunk_ -> W buffer (chunk_ & 1) by LDS-DMA
-#define ST_ISSUE_W(chunk_)                                                                 \
+#define ST_ISSUE_W(chunk_) ST_ISSUE_W_AT(chunk_, m0)
+#define ST_ISSUE_W_AT(chunk_, m0_)                                                         \
   {                                                                                        \
-    const u32x4* wsrc = p.wp + size_t(chunk_) * (18 * C::NPART) * p.cout_pad + m0;         \
+    const u32x4* wsrc = p.wp + size_t(chunk_) * (18 * C::NPART) * p.cout_pad + (m0_);      \
     u32x4* wdst = Ws + ((chunk_) & 1) * C::W_UNITS;                                        \
     _Pragma("unroll") for (int i = 0; i < C::NW; ++i) {                                    \
       const int u = i * 8 + wave;                                                          \
@@ -394,15 +406,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   }
 
   // XG: halo image of chunk_ -> X buffer (chunk_ & 1) by LDS-DMA
-#define ST_ISSUE_XG(chunk_)                                                                \
+#define ST_ISSUE_XG(chunk_) ST_ISSUE_XG_AT(chunk_, xg, xoff)
+#define ST_ISSUE_XG_AT(chunk_, xg_, xoff_)                                                 \
   {                                                                                        \
-    const u32x4* xsrc = xg + size_t(chunk_) * (2 * C::NPART) * plane_src;                  \
+    const u32x4* xsrc = (xg_) + size_t(chunk_) * (2 * C::NPART) * plane_src;               \
     u32x4* xdst = Xs + ((chunk_) & 1) * C::X_UNITS;                                        \
     _Pragma("unroll") for (int i = 0; i < C::NXW; ++i) {                                   \
       const int u = i * 8 + wave;                                                          \
       if (C::NXI % 8 == 0 || u < C::NXI)                                                   \
         __builtin_amdgcn_global_load_lds(                                                  \
-            (const __attribute__((address_space(1))) void*)(xsrc + xoff[i]),               \
+            (const __attribute__((address_space(1))) void*)(xsrc + (xoff_)[i]),            \
             (__attribute__((address_space(3))) void*)(xdst + u * 64), 16, 0, 0);           \
     }                                                                                      \
   }
@@ -434,6 +447,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NLOADS < 63 ? NLOADS : 63) : "memory")
 #define ST_BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+  const u32x4* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li;
+  const u32x4* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li;
+  bool primed = false;   // PERSIST: the first chunk of this tile was issued under the previous tile's epilogue
+  for (;;) {             // one pass unless PERSIST
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -441,9 +458,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  const u32x4* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li;
-  const u32x4* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li;
 
   // Phase schedule (PIPE = false; X and W double-buffered in LDS, ONE barrier per chunk).  In iteration c every wave
   // issues the LDS-DMA of W(c+1), converts/stores X(c+1) from the registers loaded one iteration
@@ -453,9 +467,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // matrix pipe together.
   const bool lead = __builtin_amdgcn_readfirstlane(wave) < 4;
   const int nch = p.nchunks;
-  ST_ISSUE_W(0);
+  if (!PERSIST || !primed) ST_ISSUE_W(0);
   if constexpr (XG) {
-    ST_ISSUE_XG(0);
+    if (!PERSIST || !primed) ST_ISSUE_XG(0);
   } else {
     ST_LOAD_X(0);
     ST_STORE_X(0);
@@ -490,6 +504,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     if (more2) { ST_BARRIER_KEEP_LOADS(); } else { ST_BARRIER_DRAIN(); }
   }
 
+  // PERSIST: decode the next tile and start the LDS-DMA of its first chunk (buffer 0 of both images is free after
+  // the last chunk's barrier; the epilogue's patches live behind the staging buffers)
+  int nb = 0, nm0 = 0, nx0 = 0, ny0 = 0;
+  unsigned nxoff[XG ? C::NXW : 1];
+  const u32x4* nxg = nullptr;
+  bool has_next = false;
+  if constexpr (PERSIST) {
+    has_next = tile + int(gridDim.x) < p.ntiles;
+    if (has_next) {
+      ST_DECODE_TILE(tile + int(gridDim.x), nb, nm0, nx0, ny0);
+      ST_XOFF(nb, nx0, ny0, nxg, nxoff);
+      ST_ISSUE_W_AT(0, nm0);
+      ST_ISSUE_XG_AT(0, nxg, nxoff);
+    }
+  }
+
   // ---- epilogue: bias + ReLU, NCHW store ---------------------------------------------------
   // An accumulator register is 32 consecutive x of one channel row (one dword per lane).  Stored
   // as-is that is 16 dword-store instructions per 32x32 tile, and a block with the CU to itself
@@ -502,7 +532,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     // stores 16 B per lane: 32 lanes cover 512 contiguous bytes of one channel group's row.  SPLIT: a second
     // patch / store for the lo image.
     constexpr int NPT = C::NPART;
-    unsigned* patch = reinterpret_cast<unsigned*>(smem16 + wave * (128 * NPT));
+    unsigned* patch = reinterpret_cast<unsigned*>(smem16 + (PERSIST ? 2 * C::W_UNITS + 2 * C::X_UNITS : 0) +
+                                                  wave * (128 * NPT));
     const u32x4* patch16 = reinterpret_cast<const u32x4*>(patch);
     u32x4* yg = reinterpret_cast<u32x4*>(p.y);
     const int cgroups = p.cout >> 3;
@@ -665,8 +696,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       }
     }
   }
+  if (!PERSIST || !has_next) break;
+  tile += int(gridDim.x);
+  b = nb; m0 = nm0; x0 = nx0; y0 = ny0; xg = nxg;
+#pragma unroll
+  for (int i = 0; i < (XG ? C::NXW : 1); ++i) xoff[i] = nxoff[i];
+  primed = true;
+  }   // tile loop
 }
 
+#undef ST_DECODE_TILE
+#undef ST_XOFF
+#undef ST_ISSUE_W_AT
+#undef ST_ISSUE_XG_AT
 #undef ST_LOAD_ITEM
 #undef ST_STORE_ITEM
 #undef ST_READ_TAP
@@ -722,6 +764,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
   p.vec_store = (p.ldo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
   dim3 grid((unsigned)(ptiles * p.ctiles));
+  p.ntiles = (int)(ptiles * p.ctiles);
   // PIPE schedule for the forward form (measured +2.7 % bf16, +1.3 % bf16x3 over the layer set); the gated
   // data-gradient form keeps the phase schedule (its doubled register loads make the interleave a small loss)
   if (p.cin % KC != 0)
@@ -747,7 +790,14 @@ int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
   p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
   p.vec_store = (p.ldo % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0) ? 1 : 0;
   dim3 grid((unsigned)(ptiles * p.ctiles));
-  if (xg && yg)
+  p.ntiles = (int)(ptiles * p.ctiles);
+  if (xg && yg && !SPLIT) {
+    // persistent form: one block per CU (a multiple of 8, so a block's tiles stay on its XCD's slots)
+    const bool persist = !getenv("ST_G8_NO_PERSIST");
+    dim3 pgrid((unsigned)std::min<long long>(p.ntiles, persist ? 256 : p.ntiles));
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), pgrid,
+                       dim3(NTHREADS), C::LDS_BYTES + 8 * 128 * 16, stream, p);
+  } else if (xg && yg)
     hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), grid,
                        dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else if (xg)
