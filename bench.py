@@ -57,7 +57,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 # HBM bytes per launch of the dominant kernel from profiles/r1_bench_infer_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
 # KiB, averaged over the launches of its 3-blocks-per-CU instantiation (19 of the 20 launches per inference step);
 # 4-B-per-lane loads: FETCH_SIZE taken as reported)
-DOMINANT_TRAFFIC_BYTES = (568809.0 + 248346.9) * 1024
+DOMINANT_TRAFFIC_BYTES = (568845.7 + 248346.9) * 1024
+# same file: the G8 -> G8 instantiation of the bf16 kernel (1003 launches: FETCH_SIZE + WRITE_SIZE, KiB per launch)
+DOMINANT_BF16_TRAFFIC_BYTES = (111074.2 + 131072.0) * 1024
 
 
 def encoder_decoder_flops(side: int):
@@ -306,7 +308,10 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
                                         "activations between the convs of each network"), "batch_per_gpu": args.batch, "side": args.side},
                 "model_tflops": round(value * per_img / 1e12, 2),
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": dom_name,
+                             "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                             "traffic": round(DOMINANT_BF16_TRAFFIC_BYTES)
+                             if (not x3 and args.batch == BATCH and args.side == SIDE) else None,
+                             "kernel": dom_name,
                              "mfma_flops_per_algorithmic_flop": mul,
                              "launches": len(dom), "avg_launch_us": round(sec / max(1, len(dom)) * 1e6, 2),
                              "all_conv_tflops_algorithmic": round(sum(r["flops"] for r in allconv) /

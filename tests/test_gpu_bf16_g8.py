@@ -37,6 +37,14 @@ CASES = [
     (1, 128, 64, 48, 32, False, False, False),   # no ReLU
     (3, 16, 8, 20, 20, False, True, False),      # one chunk, one channel group
     (1, 256, 512, 24, 40, False, True, False),   # four channel tiles per pixel tile
+    # more than 256 tiles: the G8 -> G8 bf16 kernel is persistent (256 blocks walk the tiles, the next tile's first
+    # chunk is prefetched under the epilogue)
+    (3, 64, 64, 320, 320, False, True, False),   # 300 tiles of 32 rows, uneven tail
+    (3, 64, 64, 320, 320, False, True, True),    # ... with the fused pool
+    (3, 64, 256, 160, 192, False, True, False),  # 360 tiles, two channel tiles, plain tile order (180 % 8 != 0)
+    (4, 32, 256, 160, 192, False, True, False),  # 480 tiles, XCD-swizzled tile order
+    (2, 128, 128, 120, 100, True, True, False),  # upsample to 240 x 200: 2 x 15 x 7 = 210 ... x 1 channel tile
+    (5, 16, 128, 150, 100, True, True, False),   # upsample to 300 x 200: 5 x 19 x 7 = 665 tiles
 ]
 
 
