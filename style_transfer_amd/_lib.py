@@ -118,7 +118,15 @@ def check(code: int, what: str = "") -> None:
         raise StHipError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device.  The raw accessors cost ~0.3 us; building a
+    torch.cuda.Stream object per launch cost ~9 us, i.e. ~2 ms of host time per training step."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
