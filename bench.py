@@ -99,7 +99,7 @@ def train_flops_per_image(side: int) -> float:
     return (2 * enc + dec + 2 * l21 + 2 * l25) + 2 * dec + (l21 + l25)
 
 
-def cpu_baseline_infer(pairs: int = 2, runs: int = 2):
+def cpu_baseline_infer(pairs: int = 8, runs: int = 3):
     """Time the CPU oracle on a bounded sample: `pairs` 512x512 content/style pairs, alpha=1."""
     from oracle import ref_ops as R
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
