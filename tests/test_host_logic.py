@@ -140,3 +140,24 @@ def test_data_parallel_gradients_equal_large_batch():
         p.join(timeout=60)
         assert p.exitcode == 0
     torch.testing.assert_close(torch.tensor(dp), torch.tensor(ref), rtol=2e-4, atol=1e-6)
+
+
+def test_g8_layout_helpers_roundtrip_on_cpu():
+    """ops.to_g8 / from_g8 (bf16 [n][c/8][h][w][8]) and the bf16x3 hi/lo pair form are pure torch: the layouts the
+    header documents, bf16 rounding for G8, an exact round trip for values that fit hi + lo."""
+    from style_transfer_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 5, 7, generator=g)
+    g8 = ops.to_g8(x)
+    assert g8.shape == (2, 2, 5, 7, 8) and g8.dtype == torch.bfloat16 and ops.is_g8(g8) and not ops.is_g8_pair(g8)
+    assert g8[1, 1, 3, 4, 5] == x[1, 13, 3, 4].to(torch.bfloat16)          # channel 8 * 1 + 5
+    assert torch.equal(ops.from_g8(g8), x.to(torch.bfloat16).float())
+    pair = ops.to_g8_pair(x)
+    assert pair.shape == (2, 2, 2, 5, 7, 8) and ops.is_g8_pair(pair) and not ops.is_g8(pair)
+    hi = x.to(torch.bfloat16)
+    assert pair[0, 1, 0, 2, 6, 3] == hi[0, 11, 2, 6]
+    assert pair[0, 1, 1, 2, 6, 3] == (x - hi.float())[0, 11, 2, 6].to(torch.bfloat16)
+    back = ops.from_g8_pair(pair)
+    assert float((back - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -16   # 16 significand bits survive
+    with pytest.raises(AssertionError):
+        ops.to_g8(torch.zeros(1, 12, 2, 2))                                 # c % 8 != 0
