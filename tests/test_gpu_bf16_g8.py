@@ -98,8 +98,9 @@ def test_g8_argument_checks(ops):
         ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, True, "replicate", True, True, y_g8=True)
 
 
-@pytest.mark.parametrize("compute", ["bf16", "bf16x3"])
-def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16(compute):
+@pytest.mark.parametrize("compute,shape", [("bf16", (2, 3, 75, 91)), ("bf16x3", (2, 3, 75, 91)),
+                                           ("bf16", (16, 3, 512, 512))])     # BASELINE configs[1] size
+def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16(compute, shape):
     """Encoder / Decoder forward in bf16 / bf16x3 mode (G8 hand-overs between the nine convs of each) against the
     same layers run one by one through the fp32-activation kernels of that mode; odd sizes so that the ceil-mode
     pools and ragged tiles are on the path."""
@@ -110,7 +111,7 @@ def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16(compute):
     dec = Decoder().cuda().eval()
     dec.load_state_dict(R.make_decoder_state(1))
     g = torch.Generator().manual_seed(3)
-    x = torch.rand(2, 3, 75, 91, generator=g).cuda()
+    x = torch.rand(*shape, generator=g).cuda()
     with torch.no_grad(), precision.compute_dtype(compute):
         feat = enc(x)
         img = dec(feat)
@@ -135,7 +136,8 @@ def test_encoder_decoder_g8_chain_is_bit_identical_to_layerwise_bf16(compute):
         wp = pack(seq[idx].weight)
         y = ops.conv3x3(y, wp, seq[idx].bias.detach(), int(seq[idx].weight.shape[0]), up, "replicate", idx != 28)
         up = idx in dec.UP_AFTER
-    assert img.dtype == torch.float32 and tuple(img.shape) == (2, 3, 80, 96) and torch.equal(img, y)
+    out_hw = tuple(8 * ((v + 7) // 8) for v in shape[2:])
+    assert img.dtype == torch.float32 and tuple(img.shape) == (shape[0], 3) + out_hw and torch.equal(img, y)
 
 
 # ---- bf16x3: hi/lo pair layout -------------------------------------------------------------------------------
