@@ -127,8 +127,9 @@ int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, const float* 
  * Sequential (generator.py:47-76, 89-117) then move 2 instead of 4 bytes per value, a G8 input is staged by
  * LDS-DMA, and the results are bit-identical to chaining st_conv3x3_fwd_bf16 / st_conv3x3_pool_fwd_bf16 (a G8
  * output is the round-to-nearest-even the next layer's staging applies anyway).  pool != 0: fused ceil-mode 2x2
- * max pool (not with upsample2x).  A G8 input needs cin % 16 == 0 and replicate padding, a G8 output
- * cout % 8 == 0; G8 buffers must be 16-byte aligned.  Forward only. */
+ * max pool (not with upsample2x).  A G8 input needs cin % 16 == 0, a G8 output cout % 8 == 0; G8 buffers must be
+ * 16-byte aligned.  Both padding modes (replicate: generator.py:19-39; zero: the loss VGG, trainer.py:165-199).
+ * Forward only. */
 int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y, int y_g8,
                            int n, int cin, int hin, int win, int cout, int upsample2x, int pad_mode, int relu,
                            int pool, st_stream_t stream);

@@ -168,22 +168,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // XG: wave w copies 1-KiB pieces u = i*8 + w of the halo image; lane -> 16-B unit (half, position) u*64 + lane,
   // source = the (clamped, optionally upsampled) pixel of channel group 2*chunk + half
   unsigned xoff[XG ? C::NXW : 1];
+  unsigned xoob = 0;     // bit i: piece i of this lane is a zero-padding position (pad_zero; patched after the DMA)
   const u32x4* xg = nullptr;
-#define ST_XOFF(b_, x0_, y0_, xg_, xoff_)                                                  \
+#define ST_XOFF(b_, x0_, y0_, xg_, xoff_, xoob_)                                           \
   {                                                                                        \
     xg_ = reinterpret_cast<const u32x4*>(p.x) + size_t(b_) * (p.cin / 8) * C::NPART * plane_src; \
+    xoob_ = 0;                                                                             \
     _Pragma("unroll") for (int i = 0; i < C::NXW; ++i) {                                   \
       int idx = min((i * 8 + wave) * 64 + lane, C::NPART * C::NITEM - 1);                  \
       const int part = idx / C::NITEM;                                                     \
       idx -= part * C::NITEM;                                                              \
       const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;                       \
       const int r = pidx / HC, cc = pidx - r * HC;                                         \
-      int cy = min(max((y0_) + r - 1, 0), p.H - 1), cx = min(max((x0_) + cc - 1, 0), p.W - 1); \
+      const int gy = (y0_) + r - 1, gx = (x0_) + cc - 1;                                   \
+      if (p.pad_zero && i * 8 + wave < C::NXI && (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W)) \
+        xoob_ |= 1u << i;                                                                  \
+      int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);                    \
       if (p.up) { cy >>= 1; cx >>= 1; }                                                    \
       xoff_[i] = unsigned(half * C::NPART + part) * unsigned(plane_src) + unsigned(cy * p.ws + cx); \
     }                                                                                      \
   }
-  if constexpr (XG) ST_XOFF(b, x0, y0, xg, xoff);
+  if constexpr (XG) ST_XOFF(b, x0, y0, xg, xoff, xoob);
 #pragma unroll
   for (int i = 0; i < (XG ? 0 : C::NP); ++i) {
     const int idx = min(tid + i * NTHREADS, C::NITEM - 1);
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       ST_MFMA_TAP(t & 1);                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                   \
     }                                                                                      \
-    ST_BARRIER_DRAIN();                                                                    \
+    if (MORE1_) { ST_BARRIER_DRAIN_XG(((chunk_) + 1) & 1); } else { ST_BARRIER_DRAIN(); }  \
   }
 
   // Workgroup barrier that does NOT drain the register loads issued after the LDS-DMA pieces:
@@ -446,6 +451,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #define ST_BARRIER_KEEP_LOADS()                                                            \
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NLOADS < 63 ? NLOADS : 63) : "memory")
 #define ST_BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  // XG with zero padding: LDS-DMA cannot mask, so it copies the clamped pixel and the lane that copied a padding
+  // position overwrites its own 16-B unit with zeros once its DMA has landed (vmcnt(0)), before the barrier that
+  // publishes the buffer.  Interior tiles have no such lane (xoob == 0).
+#define ST_BARRIER_DRAIN_XG(buf_)                                                          \
+  {                                                                                        \
+    if (xoob != 0) {                                                                       \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+      u32x4* xfix = Xs + (buf_) * C::X_UNITS;                                              \
+      _Pragma("unroll") for (int i = 0; i < C::NXW; ++i) {                                 \
+        const int u = i * 8 + wave;                                                        \
+        if ((xoob >> i) & 1u) xfix[u * 64 + lane] = u32x4{0u, 0u, 0u, 0u};                 \
+      }                                                                                    \
+    }                                                                                      \
+    ST_BARRIER_DRAIN();                                                                    \
+  }
 
   const u32x4* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li;
   const u32x4* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li;
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     ST_STORE_X(0);
     if (nch > 1) ST_LOAD_X(1);
   }
-  ST_BARRIER_DRAIN();
+  if constexpr (XG) { ST_BARRIER_DRAIN_XG(0); } else { ST_BARRIER_DRAIN(); }
   if constexpr (XG) {
     bf16x8 pa[2][MT], pb[2][NT], pal[SPLIT ? 2 : 1][MT], pbl[SPLIT ? 2 : 1][NT];
     int chunk = 0;
@@ -508,13 +528,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // the last chunk's barrier; the epilogue's patches live behind the staging buffers)
   int nb = 0, nm0 = 0, nx0 = 0, ny0 = 0;
   unsigned nxoff[XG ? C::NXW : 1];
+  unsigned nxoob = 0;
   const u32x4* nxg = nullptr;
   bool has_next = false;
   if constexpr (PERSIST) {
     has_next = tile + int(gridDim.x) < p.ntiles;
     if (has_next) {
       ST_DECODE_TILE(tile + int(gridDim.x), nb, nm0, nx0, ny0);
-      ST_XOFF(nb, nx0, ny0, nxg, nxoff);
+      ST_XOFF(nb, nx0, ny0, nxg, nxoff, nxoob);
       ST_ISSUE_W_AT(0, nm0);
       ST_ISSUE_XG_AT(0, nxg, nxoff);
     }
@@ -698,7 +719,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   }
   if (!PERSIST || !has_next) break;
   tile += int(gridDim.x);
-  b = nb; m0 = nm0; x0 = nx0; y0 = ny0; xg = nxg;
+  b = nb; m0 = nm0; x0 = nx0; y0 = ny0; xg = nxg; xoob = nxoob;
 #pragma unroll
   for (int i = 0; i < (XG ? C::NXW : 1); ++i) xoff[i] = nxoff[i];
   primed = true;
@@ -723,6 +744,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #undef ST_MFMA
 #undef ST_BARRIER_KEEP_LOADS
 #undef ST_BARRIER_DRAIN
+#undef ST_BARRIER_DRAIN_XG
 
 // OIHW fp32 -> packed bf16 [cin_pad/16][nparts][9][2 halves][cout_pad][8] (8 channels innermost: one
 // lane's 8 K values are 16 contiguous bytes; the channel half outside cout: the LDS image of a block).  nparts = 1: the rounded weight; nparts = 2 (bf16x3 mode): part 0 =
@@ -919,8 +941,7 @@ static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, co
   if (!x_g8 && !y_g8)
     return conv3x3_fwd_bf16_impl((const float*)x, w_packed, bias, (float*)y, n, cin, hin, win, cout, upsample2x,
                                  pad_mode, relu, pool, stream, split);
-  ST_REQUIRE(!x_g8 || (cin % KC == 0 && pad_mode == ST_PAD_REPLICATE),
-             "st_conv3x3_fwd_bf16_g8: a G8 input needs cin %% 16 == 0 (got %d) and replicate padding", cin);
+  ST_REQUIRE(!x_g8 || cin % KC == 0, "st_conv3x3_fwd_bf16_g8: a G8 input needs cin %% 16 == 0 (got %d)", cin);
   ST_REQUIRE(!x_g8 || reinterpret_cast<uintptr_t>(x) % 16 == 0, "st_conv3x3_fwd_bf16_g8: x must be 16-byte aligned");
   ST_REQUIRE(!y_g8 || cout % 8 == 0, "st_conv3x3_fwd_bf16_g8: a G8 output needs cout %% 8 == 0 (got %d)", cout);
   ST_REQUIRE(!y_g8 || reinterpret_cast<uintptr_t>(y) % 16 == 0, "st_conv3x3_fwd_bf16_g8: y must be 16-byte aligned");

@@ -64,6 +64,28 @@ def test_g8_in_g8_out_is_bit_identical_to_fp32_activation_kernels(ops, n, cin, c
     assert torch.equal(got32, ref)
 
 
+@pytest.mark.parametrize("compute", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("n,cin,cout,h,w,up,relu,pool", [c for c in CASES if not c[5]])
+def test_g8_zero_padding_is_bit_identical(ops, compute, n, cin, cout, h, w, up, relu, pool):
+    """Zero padding (the loss VGG's convs, trainer.py:165-199) with a G8 input: LDS-DMA copies the clamped pixel and
+    the copying lane zeroes its padding positions afterwards; same bits as the fp32-activation kernels."""
+    g = torch.Generator().manual_seed(cin + 7 * cout + h)
+    x = torch.randn(n, cin, h, w, generator=g).cuda() + 0.5         # non-zero border values
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    wp = ops.pack_conv3x3_weights(wt, False, compute)
+    if compute == "bf16":
+        xg = ops.to_g8(x)
+        xq = ops.from_g8(xg)
+    else:
+        xg, xq = ops.to_g8_pair(x), x
+    ref = ops.conv3x3_pool(xq, wp, b, cout, "zero", relu) if pool else ops.conv3x3(xq, wp, b, cout, False, "zero", relu)
+    got32 = ops.conv3x3_g8(xg, wp, b, cout, False, "zero", relu, pool, y_g8=False)
+    assert torch.equal(got32, ref)
+    got = ops.conv3x3_g8(xg, wp, b, cout, False, "zero", relu, pool, y_g8=True)
+    assert torch.equal(got, ops.to_g8(ref) if compute == "bf16" else ops.to_g8_pair(ref))
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w,up,pool", [
     (2, 3, 64, 37, 45, False, False),      # first encoder layer (channel tail) -> G8
     (1, 512, 256, 16, 24, False, False),   # first decoder layer: fp32 AdaIN output -> G8
@@ -92,8 +114,6 @@ def test_g8_argument_checks(ops):
     with pytest.raises(StHipError):            # G8 output needs cout % 8 == 0
         ops.conv3x3_g8(ops.to_g8(x), wp, b, 12, False, "replicate", True, False, y_g8=True)
     x, wp, b = _layer(ops, 1, 16, 16, 8, 8, seed=1)
-    with pytest.raises(StHipError):            # G8 input: replicate padding only
-        ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, False, "zero", True, False, y_g8=True)
     with pytest.raises(StHipError):            # pool and upsample exclude each other
         ops.conv3x3_g8(ops.to_g8(x), wp, b, 16, True, "replicate", True, True, y_g8=True)
 
