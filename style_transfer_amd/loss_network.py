@@ -19,7 +19,7 @@ from typing import Dict, List, Sequence, Union
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, precision
 from .autograd import _needs_grad, conv3x3_apply, maxpool2x2_apply
 from .generator import _PackedWeightCache
 
@@ -149,6 +149,9 @@ class VGG19FeatureExtractor(nn.Module):
         last_all = max(max(s) for s in sets)
         assert last_all <= self.last, "extractor was built for a shallower network"
         need_pre = {max(s) for s in sets if self.layout[max(s)][0] == "conv"}
+        compute = precision.get_compute_dtype()
+        if compute in ("bf16", "bf16x3") and not _needs_grad(x):
+            return self._forward_multi_g8(x, sets, last_all, need_pre, compute)
         pre: Dict[int, torch.Tensor] = {}
         post: Dict[int, torch.Tensor] = {}
         idx = 0
@@ -174,6 +177,66 @@ class VGG19FeatureExtractor(nn.Module):
                 x = maxpool2x2_apply(x, ceil_mode=False)
                 post[idx] = x
             idx += 1
+        res = []
+        for s in sets:
+            res.append([pre[i] if (i == max(s) and i in pre) else post[i] for i in s])
+        return res
+
+    def _forward_multi_g8(self, x, sets, last_all, need_pre, compute):
+        """forward_multi without gradients in a bf16 compute mode (the passes over the content and style ORIGINALS,
+        trainer.py:446-454): a conv whose output no extractor captures hands it to the next conv in the bf16
+        channel-group layout G8 (ops.conv3x3_g8, LDS-DMA staged, zero padding patched after the copy), with the
+        floor-mode 2x2 pool fused into its epilogue when the size is even (floor == ceil there); captured tensors
+        are fp32 NCHW as always.  Same bits as the fp32-activation kernels."""
+        want = {i for s in sets for i in s}
+        pre: Dict[int, torch.Tensor] = {}
+        post: Dict[int, torch.Tensor] = {}
+        x = x.contiguous()
+        idx = 0
+        while idx <= last_all:
+            kind, cin, cout = self.layout[idx]
+            if kind != "conv":
+                x = ops.maxpool2x2(x, False)
+                post[idx] = x
+                idx += 1
+                continue
+            conv = self.convs[str(idx)]
+            bias = conv.bias.detach()
+            cont = idx + 1 <= last_all                     # the in-place ReLU after this conv is part of the pass
+            if compute == "bf16x3" and 3 in (cin, cout):   # exact fp32 vector-ALU kernel (see _PackedWeightCache.get)
+                x = ops.conv3x3(x, self._packed.get(idx, conv.weight, False, "f32"), bias, cout, False, ops.PAD_ZERO,
+                                relu=cont and idx not in need_pre)
+                if idx in need_pre:
+                    pre[idx] = x
+                    if cont:
+                        x = torch.relu(x)
+                if cont:
+                    post[idx] = post[idx + 1] = x
+                    idx += 1
+                idx += 1
+                continue
+            wp = self._packed.get(idx, conv.weight, False, compute)
+            if idx in need_pre:
+                x = ops.conv3x3_g8(x, wp, bias, cout, False, ops.PAD_ZERO, relu=False, pool=False, y_g8=False)
+                pre[idx] = x
+                if cont:
+                    x = torch.relu(x)
+                    post[idx] = post[idx + 1] = x
+                    idx += 1
+                idx += 1
+                continue
+            captured = idx in want or idx + 1 in want
+            h, w = int(x.shape[-3] if ops.is_g8(x) or ops.is_g8_pair(x) else x.shape[-2]), \
+                int(x.shape[-2] if ops.is_g8(x) or ops.is_g8_pair(x) else x.shape[-1])
+            pool_next = idx + 2 <= last_all and self.layout[idx + 2][0] == "pool"
+            fuse_pool = pool_next and not captured and (idx + 2) not in want and h % 2 == 0 and w % 2 == 0
+            y_g8 = not captured and cout % 8 == 0 and (not pool_next or fuse_pool) and idx + 2 <= last_all
+            x = ops.conv3x3_g8(x, wp, bias, cout, False, ops.PAD_ZERO, relu=True, pool=fuse_pool, y_g8=y_g8)
+            if not y_g8:
+                post[idx] = post[idx + 1] = x
+            idx += 2                                        # conv + its ReLU
+            if fuse_pool:
+                idx += 1                                    # ... + the pool
         res = []
         for s in sets:
             res.append([pre[i] if (i == max(s) and i in pre) else post[i] for i in s])

@@ -179,3 +179,33 @@ def test_g8_pair_is_bit_identical_to_fp32_activation_bf16x3_kernels(ops, n, cin,
     assert ops.is_g8_pair(got) and torch.equal(got, ops.to_g8_pair(ref))
     got_b = ops.conv3x3_g8(x, wp, b, cout, up, "replicate", relu, pool, y_g8=True)     # fp32 in -> pair out
     assert torch.equal(got_b, got)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("hw", [(64, 96), (70, 90)])       # (70, 90): odd sizes after the first pool, unfused pools
+@pytest.mark.parametrize("sets", [[[21]], [[2, 7, 14, 19, 25]], [[21], [2, 7, 14, 19, 25]], [[4, 9, 16]]])
+def test_loss_vgg_no_grad_g8_path_matches_differentiable_path(compute, hw, sets):
+    """VGG19FeatureExtractor.forward_multi without gradients (content / style originals) chains uncaptured convs
+    through G8 with zero padding and fused pools; with gradients it runs the fp32-activation kernels.  Every
+    captured tensor must be the same bits."""
+    from oracle import ref_ops as R
+    from style_transfer_amd import precision
+    from style_transfer_amd.loss_network import VGG19FeatureExtractor
+    last = max(max(s) for s in sets)
+    vgg = VGG19FeatureExtractor([last], weights=R.make_loss_vgg_state(2, upto=last)).cuda()
+    g = torch.Generator().manual_seed(sum(hw))
+    x = (torch.rand(2, 3, *hw, generator=g) * 4 - 2).cuda()
+    with precision.compute_dtype(compute):
+        with torch.no_grad():
+            fast = vgg.forward_multi(x, sets)
+        slow = vgg.forward_multi(x.clone().requires_grad_(True), sets)
+    for fs, ss in zip(fast, slow):
+        assert len(fs) == len(ss)
+        for a, b in zip(fs, ss):
+            assert a.dtype == torch.float32 and a.shape == b.shape
+            if compute == "bf16":
+                assert torch.equal(a, b.detach())
+            else:
+                # bf16x3: without gradients the 3-channel first conv runs the exact fp32 vector-ALU kernel, with
+                # gradients the split MFMA kernel (generator._PackedWeightCache.get): fp32-grade agreement
+                assert float((a - b.detach()).abs().max()) <= 1e-4 * float(b.abs().max())
