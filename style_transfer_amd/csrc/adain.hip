@@ -12,6 +12,7 @@
 // Reductions are shuffle + fixed-order LDS sums: run-to-run deterministic, no float atomics.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -312,6 +313,53 @@ __global__ __launch_bounds__(NT) void meanstd_kernel(const float* __restrict__ x
   }
 }
 
+// Large planes (>= 128 KB: the loss network's 64/128-channel taps at training sizes, 256 KB - 1 MB per plane).
+// One block per plane as above would stream the plane twice with few loads in flight (measured 2.5 TB/s at batch 8,
+// 512 x 512).  Here: 1024 threads, four 16-B loads in flight per thread, ONE pass with shifted sums
+//   S1 = sum(x - K), S2 = sum((x - K)^2), K = the plane's first element,
+//   mean = K + S1/n,  m2 = S2 - S1^2/n
+// (the shift keeps the cancellation in m2 at a few ulp: |mean - K| is of the order of the standard deviation for
+// the activations this is used on; per-thread partials are 64-256 terms, then a fixed-order tree).
+constexpr int NTL = 1024;
+
+__global__ __launch_bounds__(NTL) void meanstd_big_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ mean,
+                                                         float* __restrict__ stdv, int hw, float eps) {
+  __shared__ float red[NTL / 64];
+  const size_t plane = blockIdx.x;
+  const float* p = x + plane * hw;
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+  const int n4 = hw >> 2;
+  const float K = p[0];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  int i = threadIdx.x;
+  for (; i + 3 * NTL < n4; i += 4 * NTL) {
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ldg_stream(p4 + i + k * NTL);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = v[k].x - K, b = v[k].y - K, c = v[k].z - K, d = v[k].w - K;
+      s1[k] += (a + b) + (c + d);
+      s2[k] += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  for (; i < n4; i += NTL) {
+    const float4 v = ldg_stream(p4 + i);
+    const float a = v.x - K, b = v.y - K, c = v.z - K, d = v.w - K;
+    s1[0] += (a + b) + (c + d);
+    s2[0] += (a * a + b * b) + (c * c + d * d);
+  }
+  const float S1 = st::block_sum<NTL>((s1[0] + s1[1]) + (s1[2] + s1[3]), red);
+  const float S2 = st::block_sum<NTL>((s2[0] + s2[1]) + (s2[2] + s2[3]), red);
+  if (threadIdx.x == 0) {
+    const float n = float(hw);
+    mean[plane] = K + S1 / n;
+    const float m2 = fmaxf(S2 - S1 * S1 / n, 0.f);
+    stdv[plane] = sqrtf(m2 / float(hw - 1) + eps);
+  }
+}
+
 // ---- backward --------------------------------------------------------------------------
 // out = alpha * ((x - mu_c)/sg_c * sg_s + mu_s) + (1 - alpha) * x,  sg = sqrt(var_unbiased + eps).
 // Per plane: S0 = sum g, S1 = sum g*xhat; then
@@ -443,6 +491,10 @@ extern "C" int st_meanstd_fwd(const float* x, float* mean, float* stdv, int plan
                               float eps, st_stream_t stream) {
   ST_REQUIRE(x && mean && stdv, "st_meanstd_fwd: null pointer");
   ST_REQUIRE(planes > 0 && hw > 0, "st_meanstd_fwd: bad dims planes=%d hw=%d", planes, hw);
+  if (hw >= 32768 && hw % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && !getenv("ST_MEANSTD_TWO_PASS")) {
+    hipLaunchKernelGGL(meanstd_big_kernel, dim3(planes), dim3(NTL), 0, (hipStream_t)stream, x, mean, stdv, hw, eps);
+    return st::check_launch("st_meanstd_fwd");
+  }
   hipLaunchKernelGGL(meanstd_kernel, dim3(planes), dim3(NT), 0, (hipStream_t)stream, x, mean,
                      stdv, hw, eps);
   return st::check_launch("st_meanstd_fwd");

@@ -116,6 +116,11 @@ __global__ __launch_bounds__(NT) void meanstd_loss_partial_kernel(const float* _
 }
 
 // dx_i (+)= c * [ 2(ma-mb)/P / hw  +  2(sa-sb)/P * (x_i - ma) / ((hw-1) sa) ]
+// Grid (planes, slices of BWD_SLICE elements): a 1 MB plane (64 channels at 512 x 512) is worked on by 16 blocks with
+// 16-B accesses instead of one block with dword accesses (that form ran at 2.5 TB/s on the training shapes).
+constexpr int BWD_SLICE = 16384;
+
+template <bool V4>
 __global__ __launch_bounds__(NT) void meanstd_loss_bwd_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ ma,
                                                              const float* __restrict__ sa,
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(NT) void meanstd_loss_bwd_kernel(const float* __res
                                                              const float* __restrict__ gout, float scale,
                                                              float* __restrict__ dx, int planes, int hw,
                                                              int accumulate) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
   const size_t plane = blockIdx.x;
   const float c = scale * (gout ? gout[0] : 1.f) * 2.f / float(planes);
   const float mean = ma[plane], sd = sa[plane];
@@ -131,9 +137,25 @@ __global__ __launch_bounds__(NT) void meanstd_loss_bwd_kernel(const float* __res
   const float k1 = c * (sd - sb[plane]) / (float(hw - 1) * sd);
   const float* xp = x + plane * hw;
   float* dp = dx + plane * hw;
-  for (int i = threadIdx.x; i < hw; i += NT) {
-    const float g = k0 + k1 * (xp[i] - mean);
-    dp[i] = accumulate ? dp[i] + g : g;
+  const int i0 = blockIdx.y * BWD_SLICE, i1 = min(i0 + BWD_SLICE, hw);
+  if (V4) {
+    for (int i = i0 / 4 + threadIdx.x; i < i1 / 4; i += NT) {
+      const f4 v = reinterpret_cast<const f4*>(xp)[i];
+      f4 g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = k0 + k1 * (v[k] - mean);
+      if (accumulate) {
+        const f4 d = reinterpret_cast<const f4*>(dp)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = d[k] + g[k];
+      }
+      reinterpret_cast<f4*>(dp)[i] = g;
+    }
+  } else {
+    for (int i = i0 + threadIdx.x; i < i1; i += NT) {
+      const float g = k0 + k1 * (xp[i] - mean);
+      dp[i] = accumulate ? dp[i] + g : g;
+    }
   }
 }
 
@@ -212,7 +234,14 @@ extern "C" int st_meanstd_loss_bwd(const float* x, const float* mean_a, const fl
                                    float* dx, int planes, int hw, int accumulate, st_stream_t stream) {
   ST_REQUIRE(x && mean_a && std_a && mean_b && std_b && dx, "st_meanstd_loss_bwd: null pointer");
   ST_REQUIRE(planes > 0 && hw > 0, "st_meanstd_loss_bwd: bad dims planes=%d hw=%d", planes, hw);
-  hipLaunchKernelGGL(meanstd_loss_bwd_kernel, dim3(planes), dim3(NT), 0, (hipStream_t)stream, x, mean_a,
-                     std_a, mean_b, std_b, gout, scale, dx, planes, hw, accumulate);
+  const dim3 grid((unsigned)planes, (unsigned)((hw + BWD_SLICE - 1) / BWD_SLICE));
+  ST_REQUIRE(grid.y <= 65535u, "st_meanstd_loss_bwd: plane too large (hw=%d)", hw);
+  const bool v4 = hw % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(dx) % 16 == 0;
+  if (v4)
+    hipLaunchKernelGGL(meanstd_loss_bwd_kernel<true>, grid, dim3(NT), 0, (hipStream_t)stream, x, mean_a, std_a, mean_b,
+                       std_b, gout, scale, dx, planes, hw, accumulate);
+  else
+    hipLaunchKernelGGL(meanstd_loss_bwd_kernel<false>, grid, dim3(NT), 0, (hipStream_t)stream, x, mean_a, std_a,
+                       mean_b, std_b, gout, scale, dx, planes, hw, accumulate);
   return st::check_launch("st_meanstd_loss_bwd");
 }

@@ -113,6 +113,23 @@ def test_adain_device_eps_matches_host_eps(ops):
         assert torch.equal(a, b) and torch.equal(sa, sb)
 
 
+@pytest.mark.parametrize("shape,offset", [((2, 8, 256, 256), 0.0), ((1, 4, 512, 512), 0.0), ((1, 6, 256, 128), 3.0),
+                                          ((2, 3, 192, 172), -1.5)])
+def test_mean_std_large_planes(ops, shape, offset):
+    """Planes of 128 KB and more take the one-pass kernel (shifted sums, csrc/adain.hip meanstd_big_kernel): mean and
+    unbiased std + eps against float64 (transformer.py:15-24), on post-ReLU-like data and with a mean several
+    standard deviations away from the first element."""
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.relu(torch.randn(*shape, generator=g)) * 0.8 + offset
+    x[:, :, 0, 0] = 0.0                                    # the shift K is the plane's first element
+    mean, std = ops.mean_std(x.cuda(), 1e-5)
+    xd = x.double().flatten(2)
+    ref_mean = xd.mean(dim=2).view(shape[0], shape[1], 1, 1)
+    ref_std = (xd.var(dim=2) + 1e-5).sqrt().view(shape[0], shape[1], 1, 1)
+    assert rel_err(mean, ref_mean) < 2e-6
+    assert rel_err(std, ref_std) < 1e-5
+
+
 def test_adain_golden(ops, golden_dir):
     g = np.load(os.path.join(golden_dir, "adain.npz"))
     c, s = torch.from_numpy(g["content"]), torch.from_numpy(g["style"])
