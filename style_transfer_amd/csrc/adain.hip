@@ -316,10 +316,11 @@ __global__ __launch_bounds__(NT) void meanstd_kernel(const float* __restrict__ x
 // Large planes (>= 128 KB: the loss network's 64/128-channel taps at training sizes, 256 KB - 1 MB per plane).
 // One block per plane as above would stream the plane twice with few loads in flight (measured 2.5 TB/s at batch 8,
 // 512 x 512).  Here: 1024 threads, four 16-B loads in flight per thread, ONE pass with shifted sums
-//   S1 = sum(x - K), S2 = sum((x - K)^2), K = the plane's first element,
+//   S1 = sum(x - K), S2 = sum((x - K)^2), K = the average of 64 samples spread over the plane,
 //   mean = K + S1/n,  m2 = S2 - S1^2/n
-// (the shift keeps the cancellation in m2 at a few ulp: |mean - K| is of the order of the standard deviation for
-// the activations this is used on; per-thread partials are 64-256 terms, then a fixed-order tree).
+// (K lies within a fraction of a standard deviation of the mean, so the cancellation in m2 costs a few ulp whatever
+// the data; every wave computes the same K from the same 64 loads, no barrier; per-thread partials are 64-256
+// terms, then a fixed-order tree).
 constexpr int NTL = 1024;
 
 __global__ __launch_bounds__(NTL) void meanstd_big_kernel(const float* __restrict__ x,
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(NTL) void meanstd_big_kernel(const float* __restric
   const float* p = x + plane * hw;
   const float4* p4 = reinterpret_cast<const float4*>(p);
   const int n4 = hw >> 2;
-  const float K = p[0];
+  const float K = st::wave_sum(p[size_t(threadIdx.x & 63) * size_t(hw >> 6)]) * (1.f / 64.f);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   int i = threadIdx.x;
   for (; i + 3 * NTL < n4; i += 4 * NTL) {

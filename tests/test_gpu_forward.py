@@ -117,11 +117,11 @@ def test_adain_device_eps_matches_host_eps(ops):
                                           ((2, 3, 192, 172), -1.5)])
 def test_mean_std_large_planes(ops, shape, offset):
     """Planes of 128 KB and more take the one-pass kernel (shifted sums, csrc/adain.hip meanstd_big_kernel): mean and
-    unbiased std + eps against float64 (transformer.py:15-24), on post-ReLU-like data and with a mean several
-    standard deviations away from the first element."""
+    unbiased std + eps against float64 (transformer.py:15-24), on post-ReLU-like data with an offset and an outlier
+    at the first element."""
     g = torch.Generator().manual_seed(shape[2])
     x = torch.relu(torch.randn(*shape, generator=g)) * 0.8 + offset
-    x[:, :, 0, 0] = 0.0                                    # the shift K is the plane's first element
+    x[:, :, 0, 0] = 50.0                                   # an outlier: the shift K is a 64-sample average
     mean, std = ops.mean_std(x.cuda(), 1e-5)
     xd = x.double().flatten(2)
     ref_mean = xd.mean(dim=2).view(shape[0], shape[1], 1, 1)
