@@ -57,9 +57,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 # HBM bytes per launch of the dominant kernel from profiles/r1_bench_infer_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
 # KiB, averaged over the launches of its 3-blocks-per-CU instantiation (19 of the 20 launches per inference step);
 # 4-B-per-lane loads: FETCH_SIZE taken as reported)
-DOMINANT_TRAFFIC_BYTES = (568813.3 + 248346.9) * 1024
+DOMINANT_TRAFFIC_BYTES = (568828.8 + 248346.9) * 1024
 # same file: the G8 -> G8 instantiation of the bf16 kernel (1003 launches: FETCH_SIZE + WRITE_SIZE, KiB per launch)
-DOMINANT_BF16_TRAFFIC_BYTES = (111085.7 + 131072.0) * 1024
+DOMINANT_BF16_TRAFFIC_BYTES = (111085.6 + 131072.0) * 1024
 
 
 def encoder_decoder_flops(side: int):
