@@ -1,0 +1,36 @@
+"""The driver's contract on bench.py: ONE JSON line on stdout from rank 0 with the agreed keys, a roofline object for
+the dominant kernel and (when asked) a CPU baseline.  Small shapes so that the run takes seconds; collected last."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run(
+        [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+         "--side", "128", "--train-batch", "2", "--train-side", "64", "--train-steps", "2", "--train-warmup", "1",
+         "--no-gram", "--no-cpu-baseline"],
+        capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "img/s" and d["value"] > 0 and d["dtype"] == "f32" and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["train"]["value"] > 0 and d["bf16"]["inference"]["value"] > 0 and d["bf16x3"]["inference"]["value"] > 0
