@@ -163,29 +163,15 @@ class Ctx:
         # ST_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- a code-path rehearsal of N > 1 on a 1-GPU box
         rehearsal = bool(os.environ.get("ST_BENCH_REHEARSAL"))
         dev_index = 0 if rehearsal else self.local_rank
+        if dev_index >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {self.rank} needs GPU {dev_index} but this node shows "
+                             f"{torch.cuda.device_count()} (ST_BENCH_REHEARSAL=1 runs every rank on cuda:0 over gloo)")
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
         self.dist = None
         if self.world > 1:
-            import torch.distributed as dist
-            if rehearsal:
-                dist.init_process_group("gloo")
-                # gloo's CUDA path opens a stream per collective; with both ranks on one GPU and 4 hardware
-                # queues per process those streams can wait on each other forever.  The rehearsal checks the
-                # control flow (same collectives, same order, no rank-dependent branches), so stage through host.
-                _all_reduce = dist.all_reduce
-
-                def _host_all_reduce(t, op=dist.ReduceOp.SUM, **kw):
-                    if t.is_cuda:
-                        c = t.detach().cpu()
-                        _all_reduce(c, op=op)
-                        t.copy_(c)
-                    else:
-                        _all_reduce(t, op=op)
-                dist.all_reduce = _host_all_reduce
-            else:
-                dist.init_process_group("nccl", device_id=self.dev)     # RCCL over xGMI
-            self.dist = dist
+            from style_transfer_amd.parallel import init_process_group
+            self.dist, self.dev = init_process_group(rehearsal=rehearsal, local_rank=self.local_rank)
 
     def barrier(self):
         if self.dist is not None:
@@ -425,7 +411,9 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "scaling": "weak",
             "dtype": compute, "style_loss": "VincentStyleLoss (covariance MFMA + eigh)" if use_vincent
             else "AdaINStyleLoss (mean/std)",
-            "launch": "one HIP graph replay per step (GraphedStep)" if graphed is not None else "eager launches",
+            "launch": ("eager launches" if graphed is None else "one HIP graph replay per step (GraphedStep)"
+                       if ctx.world == 1 else "three HIP graph replays per step around the two eager all-reduces "
+                                              "(GraphedStep, data parallel)"),
             "config": {"workload": ("BASELINE configs[2]: " if (compute, tb, s) == ("f32", 8, 256) else "") +
                                    f"training step batch {tb} at {s}x{s} {compute} per "
                                    "GPU: 2x encoder, AdaIN, decoder, Normalize, loss VGG19 (idx 21 / 2,7,14,19,25), "
@@ -435,6 +423,25 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
                                       "all-reduces per step" if ctx.world > 1 else "single GPU",
                        "gflop_per_image_necessary": round(per_img / 1e9, 2)},
             "model_tflops": round(value * per_img / 1e12, 2), "final_total_loss": round(total, 4)}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, exactly as the driver
+    would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), as a CHILD
+    process -- this parent never initialises the GPU, it only forwards rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=REPO)
+    for ln in proc.stdout:                      # stdout carries ONE JSON line (rank 0); anything else goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
@@ -457,6 +464,8 @@ def main():
     ap.add_argument("--no-bf16", action="store_true",
                     help="skip the bf16 (BASELINE configs[3] shape) and bf16x3 compute-mode legs")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)                # nothing in this process has touched the GPU yet
     if os.environ.get("ST_BENCH_WATCHDOG"):      # dump every thread's stack and exit if the run hangs
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["ST_BENCH_WATCHDOG"]), exit=True)
@@ -468,7 +477,7 @@ def main():
     if args.mode in ("both", "train"):
         train = run_train(ctx, args, use_vincent=False, compute=args.compute)
         if ctx.world == 1 and not args.no_hip_graph:
-            # the same step replayed from a HIP graph (single process; the N > 1 legs stay eager)
+            # the same step replayed from a HIP graph (N > 1: the graphed data-parallel leg runs last, see below)
             g = run_train(ctx, args, use_vincent=False, compute=args.compute, hip_graph=True)
             train["hip_graph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "launch")}
         if not args.no_gram:
@@ -496,6 +505,15 @@ def main():
             x3["train"] = run_train(ctx, args, use_vincent=False, compute="bf16x3",
                                     hip_graph=(ctx.world == 1 and not args.no_hip_graph))
         line["bf16x3"] = x3
+    if ctx.world > 1 and args.mode in ("both", "train") and not args.no_hip_graph:
+        # Data-parallel step replayed from three HIP graphs around the two eager all-reduces.  Last leg of the run and
+        # guarded: the eager legs above are the headline, this one must not be able to take the line down with it.
+        tgt = line["train"] if args.mode == "both" else line
+        try:
+            g = run_train(ctx, args, use_vincent=False, compute=args.compute, hip_graph=True)
+            tgt["hip_graph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "launch")}
+        except Exception as e:      # noqa: BLE001
+            tgt["hip_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline:
             if args.mode in ("both", "infer"):
@@ -510,4 +528,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

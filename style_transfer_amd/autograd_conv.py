@@ -65,6 +65,11 @@ class DecoderChainFunction(torch.autograd.Function):
     ``dy`` and the saved activation -- one full tensor read less in each of them.
 
     ``specs``: per layer (key, cout, upsample2x, relu); ``params``: w0, b0, w1, b1, ...
+
+    ``cache.direct_grads`` (set by the trainer's flat gradient bucket, trainer.GradBucket): the weight-gradient
+    kernel writes straight into the ``.grad`` the bucket pre-allocated for each parameter (a slice of ONE flat
+    buffer, all-reduced in place) and the node returns no gradient for it -- no per-parameter accumulate or copy
+    kernels.  The write OVERWRITES: valid because the trainer runs the decoder once per backward.
     """
 
     @staticmethod
@@ -96,10 +101,15 @@ class DecoderChainFunction(torch.autograd.Function):
             # except at the top of the chain, where the layer's own output would be needed -- the
             # reference's last decoder conv has no ReLU (generator.py:117), which is asserted in Decoder
             if ctx.needs_input_grad[3 + 2 * i] or ctx.needs_input_grad[4 + 2 * i]:
+                direct = (getattr(ctx.cache, "direct_grads", False) and ctx.needs_input_grad[3 + 2 * i]
+                          and ctx.needs_input_grad[4 + 2 * i] and w.grad is not None and b.grad is not None
+                          and w.grad.is_contiguous() and b.grad.is_contiguous())
                 dw, db = ops.conv3x3_wgrad(x_i, g, None, want_bias=True, upsample2x=up,
-                                           pad_mode=ops.PAD_REPLICATE, compute=ctx.compute[i])
-                grads[2 * i] = dw if ctx.needs_input_grad[3 + 2 * i] else None
-                grads[2 * i + 1] = db if ctx.needs_input_grad[4 + 2 * i] else None
+                                           pad_mode=ops.PAD_REPLICATE, compute=ctx.compute[i],
+                                           dw_out=w.grad if direct else None, db_out=b.grad if direct else None)
+                if not direct:
+                    grads[2 * i] = dw if ctx.needs_input_grad[3 + 2 * i] else None
+                    grads[2 * i + 1] = db if ctx.needs_input_grad[4 + 2 * i] else None
             if i > 0 or ctx.needs_input_grad[0]:
                 wpt = ctx.cache.get(key, w, True, ctx.compute[i])
                 gate = x_i if (i > 0 and ctx.specs[i - 1][3]) else None     # input is a ReLU output

@@ -34,10 +34,22 @@ class SymmetricPadding2D(nn.Module):
 
 
 class _PackedWeightCache:
-    """Packed (K-major) copies of OIHW conv weights; rebuilt when the parameter changes."""
+    """Packed (K-major) copies of OIHW conv weights; rebuilt when the parameter changes.
+
+    Freshness = (parameter ``_version``, its ``data_ptr``, the process-wide ``generation``).  A HIP-graph replay
+    moves weights in place through captured optimizer kernels WITHOUT bumping ``_version``; GraphedStep therefore
+    calls ``invalidate_all()`` after every replay, so an eager forward that follows (per-epoch eval, a ragged last
+    batch, ``Trainer.stylize`` after ``train()``) repacks instead of reusing a stale copy."""
+
+    generation = 0
+
+    @classmethod
+    def invalidate_all(cls) -> None:
+        cls.generation += 1
 
     def __init__(self):
         self._c: Dict[Tuple[int, bool], Tuple[int, int, torch.Tensor]] = {}
+        self.direct_grads = False     # set by the trainer: weight gradients go straight into its flat bucket
 
     def get(self, key, w: torch.Tensor, transpose_flip: bool = False, compute: Optional[str] = None,
             forward_only: bool = False) -> torch.Tensor:
@@ -48,10 +60,11 @@ class _PackedWeightCache:
             # a layer that will be differentiated stays on the split kernels so that its backward does too)
             compute = "f32"
         ent = self._c.get((key, transpose_flip, compute))
-        if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
-            return ent[2]
+        fresh = (w._version, w.data_ptr(), _PackedWeightCache.generation)
+        if ent is not None and ent[0] == fresh:
+            return ent[1]
         packed = ops.pack_conv3x3_weights(w, transpose_flip, compute)
-        self._c[(key, transpose_flip, compute)] = (w._version, w.data_ptr(), packed)
+        self._c[(key, transpose_flip, compute)] = (fresh, packed)
         return packed
 
     def clear(self):

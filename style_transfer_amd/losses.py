@@ -257,13 +257,22 @@ class HistLoss(nn.Module):
         self.histogram_block = RGBuvHistBlock(insz=max_input_size, h=histogram_size, intensity_scale=intensity_scale,
                                               method=method, hist_boundary=list(hist_boundary), device=device)
 
-    def from_hists(self, input_hist, target_hist, reduce_q=None, global_batch=None):
-        q = hellinger_sq(target_hist, input_hist)
-        if reduce_q is not None:
-            q = reduce_q(q)
-        batch = input_hist.shape[0] if global_batch is None else global_batch
+    @staticmethod
+    def q_from_hists(input_hist, target_hist):
+        """The scalar under the outer sqrt of losses.py:342-344 for THIS process's images."""
+        return hellinger_sq(target_hist, input_hist)
+
+    @staticmethod
+    def from_q(q, batch):
+        """losses.py:342-347 from the (batch-wide) scalar under the sqrt."""
         histogram_loss = (1 / np.sqrt(2.0) * (torch.sqrt(q)) / batch)
         return histogram_loss * 100
+
+    def from_hists(self, input_hist, target_hist, reduce_q=None, global_batch=None):
+        q = self.q_from_hists(input_hist, target_hist)
+        if reduce_q is not None:
+            q = reduce_q(q)
+        return self.from_q(q, input_hist.shape[0] if global_batch is None else global_batch)
 
     def forward(self, input, target, reduce_q=None, global_batch=None):
         input_hist = self.histogram_block(input)

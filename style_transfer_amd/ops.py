@@ -276,11 +276,13 @@ def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: 
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tensor], want_bias: bool = True,
-                  upsample2x: bool = False, pad_mode="replicate",
-                  compute: str = "f32") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                  upsample2x: bool = False, pad_mode="replicate", compute: str = "f32",
+                  dw_out: Optional[torch.Tensor] = None,
+                  db_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """(dW [cout,cin,3,3], dbias [cout] or None) of the fused conv layer; ``compute="bf16"`` rounds both
     GEMM operands (gated dy and the padded input) to bf16, accumulation and outputs stay fp32;
-    "bf16x3" uses the exact fp32 kernel (precision.py)."""
+    "bf16x3" uses the exact fp32 kernel (precision.py).  ``dw_out`` / ``db_out``: contiguous fp32 tensors the
+    kernel OVERWRITES instead of fresh allocations (the trainer passes slices of its flat gradient bucket)."""
     if compute == "bf16x3":
         compute = "f32"
     lib = _lib.load()
@@ -288,8 +290,16 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tens
     cout = int(dy.shape[1])
     s = 2 if upsample2x else 1
     assert tuple(dy.shape) == (n, cout, h * s, w * s), f"dy shape {tuple(dy.shape)} does not match x {tuple(x.shape)}"
-    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    if dw_out is not None:
+        assert tuple(dw_out.shape) == (cout, cin, 3, 3), f"dw_out shape {tuple(dw_out.shape)}"
+        dw = dw_out
+    else:
+        dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    if want_bias and db_out is not None:
+        assert tuple(db_out.shape) == (cout,), f"db_out shape {tuple(db_out.shape)}"
+        db = db_out
+    else:
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
     nbytes = lib.st_conv3x3_wgrad_workspace_bytes(n, cout, cin, h * s, w * s)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     ev = None

@@ -66,46 +66,81 @@ def allreduce_q(q):
     return _AllReduceSumScaledGrad.apply(q) if _dist() is not None else q
 
 
+class _InjectReducedQ(torch.autograd.Function):
+    """The same exchange cut in two, for a step replayed from HIP graphs: the all-reduce itself runs eagerly
+    BETWEEN two graphs on a static buffer ``q_sum``; this node (first thing of the second graph) hands that
+    buffer's value to the loss and sends ``world_size * dQ`` back to the local q."""
+
+    @staticmethod
+    def forward(ctx, q_local, q_sum, world):
+        ctx.world = world
+        return q_sum.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.world, None, None
+
+
 class GradBucket:
-    """One flat fp32 buffer for every trainable gradient; a single RCCL all-reduce per step."""
+    """ONE flat fp32 buffer holds every trainable gradient: each parameter's ``.grad`` is a view into it
+    (no pack / unpack copies), the data-parallel exchange is a single in-place RCCL all-reduce of the buffer
+    (decoder + 2 AdaIN eps = 14.02 MB), zeroing it is one memset."""
 
     def __init__(self, params: List[nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat: Optional[torch.Tensor] = None
+        self._views: List[torch.Tensor] = []
 
-    def reduce_mean(self):
-        dist = _dist()
-        if dist is None or dist.get_world_size() == 1:
-            return
+    def attach(self) -> None:
+        """(Re-)point every ``.grad`` at its slice of the flat buffer.  Cheap when nothing changed (a pointer
+        comparison per parameter); a ``zero_grad(set_to_none=True)`` by a caller is repaired here."""
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self._views, off = [], 0
+            for p in self.params:
+                self._views.append(self.flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+        for p, v in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    def zero(self) -> None:
+        self.attach()
+        self.flat.zero_()
+
+    def all_reduce_sum(self) -> None:
+        dist = _dist()
+        if dist is not None and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+    def reduce_mean(self) -> None:
+        """Stand-alone mean all-reduce of whatever gradients the parameters hold (the training step uses
+        ``zero`` / ``all_reduce_sum`` and folds the 1 / world_size into its update phase)."""
+        dist = _dist()
+        if dist is None or dist.get_world_size() == 1:
+            return
+        held = [p.grad for p in self.params]
+        self.attach()
+        for g, v in zip(held, self._views):
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+        self.all_reduce_sum()
         self.flat.div_(dist.get_world_size())
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].reshape(p.shape).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].reshape(p.shape))
-            off += n
 
 
 # ---------------------------------------------------------------------------------------------
 # the step engine (hot path)
 # ---------------------------------------------------------------------------------------------
 class StyleTransferStep:
-    """Forward half of the train-step body (trainer.py:426-464) + compute_loss (:246-279)."""
+    """Forward half of the train-step body (trainer.py:426-464) + compute_loss (:246-279).
+
+    The loss is produced in two stages so that a data-parallel step has exactly one place where ranks talk in
+    the forward: ``forward_partials`` (everything up to the per-rank scalars q under HistLoss's outer sqrt) and
+    ``combine`` (the rest, given the batch-wide q)."""
 
     def __init__(self, encoder: Encoder, decoder: Decoder, transformer: AdaIN, loss_vgg: VGG19FeatureExtractor,
                  content_layers_idx: List[int], style_layers_idx: List[int], alpha: float, beta: float, gamma: float,
@@ -122,9 +157,9 @@ class StyleTransferStep:
         self.hist_loss = HistLoss()
         self.norm = Normalize(IMAGENET_MEAN, IMAGENET_STD)
 
-    def compute_loss(self, content_features, style_features, stylized_outputs, style_imgs, content_imgs,
-                     global_batch: Optional[int] = None):
-        """Trainer.compute_loss: *_features are lists of {"model_output", "orginal"} dicts."""
+    def partial_losses(self, content_features, style_features, stylized_outputs, style_imgs, content_imgs):
+        """First stage of Trainer.compute_loss: (content, style, variation, q[2]) where q = the local sums under
+        the sqrt of the two Hellinger terms (stylised vs style, stylised vs content)."""
         loss_content = sum(self.content_loss(f['model_output'], f['orginal']) for f in content_features)
         loss_style = sum(self.style_loss(f['model_output'], f['orginal']) for f in style_features)
         variation_loss = self.variation_loss(stylized_outputs)
@@ -132,14 +167,26 @@ class StyleTransferStep:
         stylized_hist = blk(stylized_outputs)             # computed once, used by both terms
         with torch.no_grad():
             style_hist, content_hist = blk(style_imgs), blk(content_imgs)
-        histogram_loss_S = self.hist_loss.from_hists(stylized_hist, style_hist, allreduce_q, global_batch)
-        histogram_loss_C = self.hist_loss.from_hists(stylized_hist, content_hist, allreduce_q, global_batch)
-        histogram_loss = 0.4 * histogram_loss_S + 0.6 * histogram_loss_C
+        q = torch.stack([self.hist_loss.q_from_hists(stylized_hist, style_hist),
+                         self.hist_loss.q_from_hists(stylized_hist, content_hist)])
+        return loss_content, loss_style, variation_loss, q
+
+    def combine(self, partials, q_sum, batch: int):
+        """Second stage: the five scalars of Trainer.compute_loss (trainer.py:269-279)."""
+        loss_content, loss_style, variation_loss, _ = partials
+        histogram_loss = 0.4 * self.hist_loss.from_q(q_sum[0], batch) + 0.6 * self.hist_loss.from_q(q_sum[1], batch)
         total_loss = self.alpha * loss_content + self.beta * loss_style + self.gamma * variation_loss \
             + self.delta * histogram_loss
         return loss_content, loss_style, variation_loss, histogram_loss, total_loss
 
-    def forward_losses(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, global_batch: Optional[int] = None):
+    def compute_loss(self, content_features, style_features, stylized_outputs, style_imgs, content_imgs,
+                     global_batch: Optional[int] = None):
+        """Trainer.compute_loss: *_features are lists of {"model_output", "orginal"} dicts."""
+        partials = self.partial_losses(content_features, style_features, stylized_outputs, style_imgs, content_imgs)
+        batch = stylized_outputs.shape[0] if global_batch is None else global_batch
+        return self.combine(partials, allreduce_q(partials[3]), batch)
+
+    def forward_partials(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor):
         with torch.no_grad():                              # frozen encoder: forward only
             if content_imgs.shape == style_imgs.shape:
                 # one pass over [content; style]: same kernels, same per-image results (no cross-image op in
@@ -161,40 +208,106 @@ class StyleTransferStep:
         # the reference indexes the getter's layer-ordered outputs by position (trainer.py:448-457)
         content_features = [{"orginal": o, "model_output": g} for o, g in zip(org_content, gen_content)]
         style_features = [{"orginal": o, "model_output": g} for o, g in zip(org_style, gen_style)]
-        return self.compute_loss(content_features, style_features, decode_n, style_n, content_n, global_batch)
+        return self.partial_losses(content_features, style_features, decode_n, style_n, content_n)
+
+    def forward_losses(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, global_batch: Optional[int] = None):
+        partials = self.forward_partials(content_imgs, style_imgs)
+        batch = content_imgs.shape[0] if global_batch is None else global_batch
+        return self.combine(partials, allreduce_q(partials[3]), batch)
 
 
 # ---------------------------------------------------------------------------------------------
 class GraphedStep:
-    """One training step captured in a HIP graph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replayed.
+    """One training step captured in HIP graphs (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replayed.
 
     A step is ~400 kernel launches through ctypes plus the autograd tape; at small shapes (or on a busy host)
     the GPU waits for the host.  Every launch of the step goes to torch's current stream, the step has no
-    host read in it (AdaIN's eps stays on the device), workspaces come from torch's allocator -- so the whole
-    optimize_step (forward, losses, backward, optimizer) records into one graph; a replay costs ~0.1 ms of
-    host time.  Inputs are copied into static buffers; the returned losses are static tensors overwritten by
-    every replay.  Needs an optimizer built with ``capturable=True`` (Trainer does that when
-    ``use_hip_graph`` is set) and a fixed batch shape: other shapes run eagerly.  Single-process only for
-    now: with world_size > 1 the step runs eagerly (the all-reduce is not captured)."""
+    host read in it (AdaIN's eps stays on the device), workspaces come from torch's allocator -- so it records
+    into graphs and a replay costs ~0.1 ms of host time.
+
+    Single process: ONE graph holds the whole optimize_step.  Data parallel (world_size > 1): the step has two
+    exchanges (the 2-float Hellinger sums in the forward, the flat gradient bucket after the backward), so it
+    is THREE graphs sharing one memory pool with the two eager all-reduces between them::
+
+        graph A  zero the bucket, forward up to the local q        (Trainer.step_forward)
+        eager    all-reduce(q_sum[2])
+        graph B  rest of the loss, backward into the bucket        (Trainer.step_backward)
+        eager    all-reduce(bucket)
+        graph C  1/world, AdaIN grad clamp, optimizer.step()       (Trainer.step_update)
+
+    The autograd tape built while graph A records lives on the host only during the capture; graph B records the
+    backward kernels it drives, reading the activations graph A left in the shared pool.
+
+    Inputs are copied into static buffers; the returned losses are static tensors overwritten by every replay.
+    Needs an optimizer built with ``capturable=True`` (Trainer does that when ``use_hip_graph`` is set) and a
+    fixed batch shape: other shapes run eagerly."""
 
     WARMUP = 3
 
     def __init__(self, trainer: "Trainer", step: StyleTransferStep, optimizer, bucket: GradBucket):
         self.trainer, self.step, self.optimizer, self.bucket = trainer, step, optimizer, bucket
         self.graph = None
+        self.graphs = []
         self.shape = None
         self.static_content = self.static_style = None
         self.losses = None
+        self.q_sum = None
         self.eager_calls = 0
+        self.replays = 0
         self._side = None
 
     def _eager(self, content, style):
         return self.trainer.optimize_step(self.step, self.optimizer, self.bucket, content, style)
 
+    def _capture(self):
+        tr, dist = self.trainer, _dist()
+        torch.cuda.synchronize()
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # side-stream warm-up: intended
+        self.bucket.attach()
+        if tr.world_size == 1:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.losses = self._eager(self.static_content, self.static_style)
+            self.graphs = [graph]
+        else:
+            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # thread-local capture mode: the process group's watchdog thread may query events while we record
+            mode = dict(capture_error_mode="thread_local")
+            with torch.cuda.graph(ga, **mode):
+                partials = tr.step_forward(self.step, self.bucket, self.static_content, self.static_style)
+                self.q_sum = partials[3].detach().clone()
+            dist.all_reduce(self.q_sum, op=dist.ReduceOp.SUM)     # same collective sequence as every later step
+            with torch.cuda.graph(gb, pool=ga.pool(), **mode):
+                self.losses = tr.step_backward(self.step, partials, self.q_sum,
+                                               self.static_content.shape[0] * tr.world_size)
+            del partials
+            self.bucket.all_reduce_sum()
+            with torch.cuda.graph(gc, pool=ga.pool(), **mode):
+                tr.step_update(self.step, self.optimizer, self.bucket)
+            self.graphs = [ga, gb, gc]
+        self.graph = self.graphs[0]
+        torch.cuda.synchronize()
+
+    def _replay(self):
+        if len(self.graphs) == 1:
+            self.graphs[0].replay()
+        else:
+            dist = _dist()
+            ga, gb, gc = self.graphs
+            ga.replay()
+            dist.all_reduce(self.q_sum, op=dist.ReduceOp.SUM)
+            gb.replay()
+            self.bucket.all_reduce_sum()
+            gc.replay()
+        self.replays += 1
+        from .generator import _PackedWeightCache
+        _PackedWeightCache.invalidate_all()        # weights moved without a ._version bump (ADVICE r1)
+
     def __call__(self, content: torch.Tensor, style: torch.Tensor):
         key = (tuple(content.shape), tuple(style.shape))
-        if self.trainer.world_size > 1 or (self.shape is not None and key != self.shape):
-            return self._eager(content, style)            # ragged last batch / data parallel: eager
+        if self.shape is not None and key != self.shape:
+            return self._eager(content, style)            # ragged last batch: eager
         if self.graph is None:
             if self.eager_calls < self.WARMUP:             # allocator, packed-weight caches, optimizer state
                 # Warm-up steps run on a side stream (the PyTorch capture recipe): autograd's AccumulateGrad
@@ -213,19 +326,12 @@ class GraphedStep:
                 return out
             self.shape = key
             self.static_content, self.static_style = content.clone(), style.clone()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
-                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # side-stream warm-up: intended
-            self.optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                self.losses = self._eager(self.static_content, self.static_style)
-            self.graph = graph
+            self._capture()
             # the capture recorded the step without running it: the replay below IS this call's step
         else:
             self.static_content.copy_(content, non_blocking=True)
             self.static_style.copy_(style, non_blocking=True)
-        self.graph.replay()
+        self._replay()
         return self.losses
 
 
@@ -306,13 +412,21 @@ class Trainer:
         except TypeError:
             raise TypeError("Invalid argument for optimizer!")
 
-    _CAPTURABLE = ('adam', 'adamw', 'adamax', 'adagrad', 'adadelta', 'rmsprop', 'rprop')
+    @staticmethod
+    def _capturable(optimizer_name: str) -> bool:
+        """Does this torch optimizer take ``capturable=True`` (state and step count on the device)?"""
+        import inspect
+        cls = {'sgd': optim.SGD, 'adam': optim.Adam, 'rmsprop': optim.RMSprop, 'adagrad': optim.Adagrad,
+               'adadelta': optim.Adadelta, 'adamw': optim.AdamW, 'adamax': optim.Adamax, 'rprop': optim.Rprop
+               }.get(optimizer_name.lower())
+        return cls is not None and 'capturable' in inspect.signature(cls.__init__).parameters
 
     def graph_capable(self) -> bool:
-        """HIP-graph replay of the step: asked for, single process, a capturable torch optimizer and no
-        rocSOLVER eigendecomposition (VincentStyleLoss) in the step."""
-        return (self.use_hip_graph and self.world_size == 1 and not self.use_VincentStyleLoss
-                and self.device.type == 'cuda' and self.optim_name['optim_name'].lower() in self._CAPTURABLE)
+        """HIP-graph replay of the step: asked for, a capturable torch optimizer and no rocSOLVER
+        eigendecomposition (VincentStyleLoss) in the step.  Data parallel included (GraphedStep: three graphs
+        around the two eager all-reduces)."""
+        return (self.use_hip_graph and not self.use_VincentStyleLoss
+                and self.device.type == 'cuda' and self._capturable(self.optim_name['optim_name']))
 
     def graph_optim_kwargs(self) -> dict:
         """Optimizer kwargs for graph replay: ``capturable=True`` (optimizer state and step count on the device)."""
@@ -407,6 +521,7 @@ class Trainer:
                               f" switching to {ck_name}")
                 self.optim_name['optim_name'] = ck_name
             transformer_optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+            self._retarget_optimizer(transformer_optimizer)
         except Exception:
             raise RuntimeError("Unable to load optimizer state!")
         try:
@@ -429,6 +544,36 @@ class Trainer:
             warnings.warn("Checkpoint missing train process info!")
         return transformer_optimizer, init_epoch, loss_list, completed_step, last_session_epoch
 
+    def _retarget_optimizer(self, optimizer) -> None:
+        """``load_state_dict`` overwrites ``param_groups`` with the checkpoint's: a checkpoint written by an eager
+        run has ``capturable=False``, a float lr and host-side step counters, one written by a graph run the
+        opposite.  Put the loaded optimizer into the form THIS run needs (graph replay: capturable, lr and step
+        counters on the device so the scheduler's ``lr.fill_`` reaches the captured kernels; eager: plain floats)."""
+        graph = self.graph_capable()
+        for group in optimizer.param_groups:
+            lr = group['lr']
+            if graph:
+                group['capturable'] = True
+                if not isinstance(lr, torch.Tensor):
+                    group['lr'] = torch.tensor(float(lr), dtype=torch.float32, device=self.device)
+                elif lr.device != self.device:
+                    group['lr'] = lr.to(self.device)
+                if 'initial_lr' in group and isinstance(group['initial_lr'], torch.Tensor):
+                    group['initial_lr'] = float(group['initial_lr'])
+            else:
+                if 'capturable' in group:
+                    group['capturable'] = False
+                if isinstance(lr, torch.Tensor):
+                    group['lr'] = float(lr)
+                if isinstance(group.get('initial_lr'), torch.Tensor):
+                    group['initial_lr'] = float(group['initial_lr'])
+        for p, st in optimizer.state.items():
+            step = st.get('step')
+            if isinstance(step, torch.Tensor):
+                want = p.device if graph else torch.device('cpu')
+                if step.device != want:
+                    st['step'] = step.to(want)
+
     # ---- training -------------------------------------------------------------------------
     def make_step(self, encoder, decoder, transformer, loss_vgg) -> StyleTransferStep:
         return StyleTransferStep(encoder, decoder, transformer, loss_vgg, self.content_layers_idx,
@@ -444,18 +589,43 @@ class Trainer:
                 p.requires_grad_(False)                   # never read by an optimizer (trainer.py:292-297)
         return params
 
-    def optimize_step(self, step: StyleTransferStep, optimizer, bucket: GradBucket, content_imgs, style_imgs):
-        """zero_grad / backward / [grad all-reduce] / [AdaIN grad clamp] / optimizer.step (trainer.py:471-473, 392-394)."""
-        global_batch = content_imgs.shape[0] * self.world_size
-        losses = step.forward_losses(content_imgs, style_imgs, global_batch)
-        optimizer.zero_grad()
+    # The step in three phases with the two data-parallel exchanges between them (GraphedStep replays each phase
+    # from its own HIP graph; eager steps call them back to back).
+    def step_forward(self, step: StyleTransferStep, bucket: GradBucket, content_imgs, style_imgs):
+        """zero_grad (one memset of the flat bucket) + the forward up to the per-rank Hellinger sums."""
+        bucket.zero()
+        step.decoder._packed.direct_grads = True       # weight gradients are written straight into the bucket
+        return step.forward_partials(content_imgs, style_imgs)
+
+    def step_backward(self, step: StyleTransferStep, partials, q_sum, global_batch: int):
+        """Rest of compute_loss from the batch-wide q, then backward into the bucket (trainer.py:472)."""
+        q = _InjectReducedQ.apply(partials[3], q_sum, self.world_size) if self.world_size > 1 else partials[3]
+        losses = step.combine(partials, q, global_batch)
         losses[4].backward()
-        bucket.reduce_mean()
+        return losses
+
+    def step_update(self, step: StyleTransferStep, optimizer, bucket: GradBucket):
+        """[1 / world_size] / [AdaIN grad clamp, AFTER the reduction] / optimizer.step (trainer.py:392-394, 473)."""
+        if self.world_size > 1:
+            bucket.flat.div_(self.world_size)
         if self.gradient_threshold is not None:
             for p in step.transformer.parameters():
                 if p.grad is not None:
                     p.grad.clamp_(-self.gradient_threshold, self.gradient_threshold)
         optimizer.step()
+
+    def optimize_step(self, step: StyleTransferStep, optimizer, bucket: GradBucket, content_imgs, style_imgs):
+        """zero_grad / backward / [grad all-reduce] / [AdaIN grad clamp] / optimizer.step (trainer.py:471-473, 392-394)."""
+        partials = self.step_forward(step, bucket, content_imgs, style_imgs)
+        q_sum = partials[3]
+        if self.world_size > 1:
+            dist = _dist()
+            q_sum = partials[3].detach().clone()
+            dist.all_reduce(q_sum, op=dist.ReduceOp.SUM)
+        losses = self.step_backward(step, partials, q_sum, content_imgs.shape[0] * self.world_size)
+        if self.world_size > 1:
+            bucket.all_reduce_sum()
+        self.step_update(step, optimizer, bucket)
         return losses
 
     def train(self):

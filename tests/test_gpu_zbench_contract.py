@@ -34,3 +34,26 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["train"]["value"] > 0 and d["bf16"]["inference"]["value"] > 0 and d["bf16x3"]["inference"]["value"] > 0
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (a torch.distributed.run child,
+    started before the parent touches the GPU) and forwards rank 0's ONE JSON line.  ST_BENCH_REHEARSAL=1: both ranks
+    on cuda:0 over gloo (this box has one GPU); the data-parallel training legs -- eager and the three-graph replay --
+    run their real collectives."""
+    env = dict(os.environ, ST_BENCH_REHEARSAL="1", ST_BENCH_PREWARM="0.05")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+         "--side", "64", "--train-batch", "2", "--train-side", "64", "--train-steps", "2", "--train-warmup", "1",
+         "--no-gram", "--no-bf16"],
+        capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["train"]["n_gpus"] == 2 and d["train"]["value"] > 0
+    assert "dp2" in d["train"]["config"]["parallelism"]
+    assert d["train"]["hip_graph"].get("value", 0) > 0, d["train"]["hip_graph"]
+    assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
