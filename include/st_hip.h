@@ -275,6 +275,21 @@ size_t st_rgbuv_hist_workspace_bytes(int n, int h, int w, int insz);
 int st_rgbuv_hist_fwd(const float* x, float* hist, float* totals, float* workspace, int n, int c,
                       int h, int w, int insz, int method, float sigma, const double* bins_host,
                       int nbins, int intensity_scale, st_stream_t stream);
+/* The same forward for callers that CANNOT ALLOCATE (code under HIP-graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc): no workspace argument -- the pixel records and the split slabs live in a file-scope
+ * __device__ array inside the library, ST_HIST_STATIC_SCRATCH_BYTES per GPU the library runs on, held until the
+ * process ends.  This entry point has NO counterpart in the reference; same kernels and bit-identical results as
+ * st_rgbuv_hist_fwd.  It calls no hipMalloc / hipFree or any allocating routine; the first call on a device
+ * resolves the array's device address (hipGetSymbolAddress, that device must be current), so make that first call
+ * outside a stream capture.  Shapes whose workspace exceeds the buffer are rejected with ST_ERR_BAD_ARG (HistLoss
+ * shapes: any batch of up to 32 images per call; st_rgbuv_hist_static_scratch_bytes() reports the limit).
+ * Every call on one GPU shares that GPU's buffer: calls that overlap on one GPU (two streams, two threads)
+ * race -- serialise them.  Nothing in the buffer has to start at zero: each call writes everything it reads. */
+#define ST_HIST_STATIC_SCRATCH_BYTES (32u << 20)
+size_t st_rgbuv_hist_static_scratch_bytes(void);
+int st_rgbuv_hist_fwd_static(const float* x, float* hist, float* totals, int n, int c, int h, int w, int insz,
+                             int method, float sigma, const double* bins_host, int nbins,
+                             int intensity_scale, st_stream_t stream);
 /* dx (+)= gout*scale * d<ghist, hist>/dx, through normalisation, kernel weights, log-chroma,
  * intensity, bilinear resize and clamp.  hist/totals: the forward outputs. */
 int st_rgbuv_hist_bwd(const float* x, const float* hist, const float* totals, const float* ghist,

@@ -76,6 +76,9 @@ SIGNATURES = {
     "st_rgbuv_hist_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "st_rgbuv_hist_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p, c_int, c_int, c_void_p]),
+    "st_rgbuv_hist_static_scratch_bytes": (c_size_t, []),
+    "st_rgbuv_hist_fwd_static": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_float, c_void_p, c_int, c_int, c_void_p]),
     "st_rgbuv_hist_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int,
                                   c_void_p]),

@@ -14,6 +14,7 @@
 // intensity_scale = 0 they are exact integer counts (each product is 0 or 1, sums < 2^24).
 // The backward pass is the same structure with two 64x64x64 MFMA products per chunk.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 
 #include "common.h"
@@ -463,6 +464,34 @@ int fill_params(HistParams& hp, int method, float sigma, const double* bins_host
 
 constexpr size_t BWD_LDS = size_t(2 * HB * LS + 2 * CH * LS + HB + 6 * CH) * sizeof(float);
 
+// floats of the forward-only workspace: pixel records + split slabs
+size_t fwd_elems(int n, const Geo& g) { return rec_elems(n, g.N) + size_t(g.nsplit) * n * 3 * HB * HB; }
+
+// ---- the library's own scratch for st_rgbuv_hist_fwd_static (callers that cannot allocate) ------------
+// One copy per GPU the library runs on, held until the process ends.  In HOST code the array's name is only a
+// stand-in for the symbol: the device address comes from hipGetSymbolAddress, once per device.
+constexpr size_t STATIC_SCRATCH_FLOATS = size_t(ST_HIST_STATIC_SCRATCH_BYTES) / sizeof(float);
+constexpr int MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[STATIC_SCRATCH_FLOATS];
+std::atomic<float*> scratch_ptr[MAX_DEVICES];
+
+// device address of `scratch` on the CURRENT device (resolved on the first call per device, then cached)
+int static_scratch(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return st::fail(ST_ERR_LAUNCH, "st_rgbuv_hist_fwd_static: hipGetDevice: %s", hipGetErrorString(e));
+  ST_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "st_rgbuv_hist_fwd_static: device %d out of range", dev);
+  float* p = scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p)
+      return st::fail(ST_ERR_LAUNCH, "st_rgbuv_hist_fwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+    scratch_ptr[dev].store(p, std::memory_order_release);   // every thread resolves the same address
+  }
+  *out = p;
+  return ST_OK;
+}
+
 }  // namespace
 
 extern "C" size_t st_rgbuv_hist_workspace_bytes(int n, int h, int w, int insz) {
@@ -499,6 +528,28 @@ extern "C" int st_rgbuv_hist_fwd(const float* x, float* hist, float* totals, flo
   hipLaunchKernelGGL(hist_sum_slabs_kernel, dim3(HIST_PARTS, n), dim3(NT), 0, s, slabs, g.nsplit, n, hist, rec);
   hipLaunchKernelGGL(hist_normalize_kernel, dim3(HIST_PARTS, n), dim3(NT), 0, s, hist, rec, totals);
   return st::check_launch("st_rgbuv_hist_fwd");
+}
+
+extern "C" size_t st_rgbuv_hist_static_scratch_bytes(void) { return ST_HIST_STATIC_SCRATCH_BYTES; }
+
+extern "C" int st_rgbuv_hist_fwd_static(const float* x, float* hist, float* totals, int n, int c, int h, int w,
+                                        int insz, int method, float sigma, const double* bins_host, int nbins,
+                                        int intensity_scale, st_stream_t stream) {
+  ST_REQUIRE(n > 0 && c >= 3 && h > 0 && w > 0 && insz > 0, "st_rgbuv_hist_fwd_static: bad dims n=%d c=%d h=%d w=%d",
+             n, c, h, w);
+  const size_t need = fwd_elems(n, geometry(n, h, w, insz)) * sizeof(float);
+  ST_REQUIRE(need <= size_t(ST_HIST_STATIC_SCRATCH_BYTES),
+             "st_rgbuv_hist_fwd_static: n=%d images of %dx%d need %zu bytes of scratch, the library's static buffer "
+             "holds %zu (use st_rgbuv_hist_fwd with a caller workspace)", n, h, w, need,
+             size_t(ST_HIST_STATIC_SCRATCH_BYTES));
+  float* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != ST_OK) return rc;
+  // same kernels as st_rgbuv_hist_fwd; every float of the scratch that is read has been written by this call
+  // (prep fills the records, every accumulate block stores its whole slab, the slab sum writes the partial totals),
+  // so nothing left over from an earlier, larger call can leak into a result
+  return st_rgbuv_hist_fwd(x, hist, totals, ws, n, c, h, w, insz, method, sigma, bins_host, nbins, intensity_scale,
+                           stream);
 }
 
 extern "C" int st_rgbuv_hist_bwd(const float* x, const float* hist, const float* totals,

@@ -1,0 +1,73 @@
+"""The entry point that allocates nothing (st_rgbuv_hist_fwd_static, include/st_hip.h): its scratch is a file-scope
+__device__ array inside libst_hip.so instead of a caller workspace.  Called through the C ABI, two calls in a row
+(the second with a smaller input, so left-overs of the first would show), each compared bit for bit with
+st_rgbuv_hist_fwd on the same input; then the size limit and the no-allocation claim."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BINS = [float(v) for v in np.linspace(-3, 3, num=64)]
+
+
+def _call(lib, x, static, method=0, intensity_scale=1, insz=128):
+    from style_transfer_amd import _lib
+    n, c, h, w = (int(v) for v in x.shape)
+    hist = torch.full((n, 3, 64, 64), float("nan"), device=x.device)
+    totals = torch.full((n,), float("nan"), device=x.device)
+    barr = (ctypes.c_double * 64)(*BINS)
+    bins = ctypes.cast(barr, ctypes.c_void_p)
+    if static:
+        rc = lib.st_rgbuv_hist_fwd_static(_lib.dev_ptr(x), _lib.dev_ptr(hist), _lib.dev_ptr(totals), n, c, h, w, insz,
+                                          method, 0.02, bins, 64, intensity_scale, _lib.stream_ptr())
+    else:
+        ws = torch.empty(lib.st_rgbuv_hist_workspace_bytes(n, h, w, insz) // 4, device=x.device)
+        rc = lib.st_rgbuv_hist_fwd(_lib.dev_ptr(x), _lib.dev_ptr(hist), _lib.dev_ptr(totals), _lib.dev_ptr(ws), n, c, h, w,
+                                   insz, method, 0.02, bins, 64, intensity_scale, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    return rc, hist, totals
+
+
+def test_static_scratch_histogram_matches_workspace_entry_point_on_two_calls():
+    from style_transfer_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(17)
+    big = torch.rand(8, 3, 256, 256, generator=g).cuda()           # resized to 128 x 128: 17.4 MB of scratch
+    small = (torch.rand(2, 3, 40, 56, generator=g) * 1.2 - 0.1).cuda()   # no resize, ragged last chunk, clamped values
+    for x in (big, small):                                          # second call: smaller input, same scratch
+        rc_ref, h_ref, t_ref = _call(lib, x, static=False)
+        before = torch.cuda.memory_stats()["allocation.all.allocated"]
+        rc, h, t = _call(lib, x, static=True)
+        assert rc == 0 and rc_ref == 0, lib.st_last_error()
+        # torch's allocator served exactly the two outputs (hist, totals); the library itself never allocates
+        assert torch.cuda.memory_stats()["allocation.all.allocated"] - before == 2
+        assert torch.equal(h, h_ref) and torch.equal(t, t_ref)
+        assert torch.isfinite(h).all() and torch.allclose(h.sum(dim=(1, 2, 3)), torch.ones(x.shape[0], device="cuda"),
+                                                          atol=1e-4)
+    # integer-count mode through the static entry point as well: exact counts, identical to the workspace form
+    rc_ref, h_ref, t_ref = _call(lib, big, static=False, method=2, intensity_scale=0)
+    rc, h, t = _call(lib, big, static=True, method=2, intensity_scale=0)
+    assert rc == 0 and torch.equal(h, h_ref) and torch.equal(t, t_ref)
+    assert torch.equal(t, t.round())
+
+
+def test_static_scratch_rejects_what_does_not_fit():
+    from style_transfer_amd import _lib
+    lib = _lib.load()
+    assert lib.st_rgbuv_hist_static_scratch_bytes() == 32 << 20
+    x = torch.zeros(1, 3, 8, 8, device="cuda")
+    hist = torch.zeros(1, 3, 64, 64, device="cuda")
+    tot = torch.zeros(1, device="cuda")
+    barr = (ctypes.c_double * 64)(*BINS)
+    # 64 images of 128 x 128 need more than the 32 MiB the library holds: refused before anything is launched
+    rc = lib.st_rgbuv_hist_fwd_static(_lib.dev_ptr(x), _lib.dev_ptr(hist), _lib.dev_ptr(tot), 64, 3, 128, 128, 128, 0, 0.02,
+                                      ctypes.cast(barr, ctypes.c_void_p), 64, 1, _lib.stream_ptr())
+    assert rc == -1 and b"static buffer" in lib.st_last_error()
+    # a 32-image batch fits (HistLoss shapes)
+    xs = torch.rand(32, 3, 128, 128, device="cuda")
+    rc, h, t = _call(lib, xs, static=True)
+    rc_ref, h_ref, t_ref = _call(lib, xs, static=False)
+    assert rc == 0 and torch.equal(h, h_ref)
