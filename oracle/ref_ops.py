@@ -361,6 +361,24 @@ def tv_loss(img: torch.Tensor) -> torch.Tensor:
 
 
 HIST_EPS = 1e-6  # losses.py:119
+#: dtype the kernel weights are cast to before the [h,N]x[N,h] product: float32 in the reference
+#: (losses.py:239-240).  Tests that use a float64 run of this oracle as an ARBITER between two fp32
+#: implementations switch it to float64 (``with hist_kernel_dtype(torch.float64)``) so that the whole
+#: computation is double precision; nothing else changes.
+HIST_KERNEL_DTYPE = torch.float32
+
+
+class hist_kernel_dtype:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global HIST_KERNEL_DTYPE
+        self.prev, HIST_KERNEL_DTYPE = HIST_KERNEL_DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global HIST_KERNEL_DTYPE
+        HIST_KERNEL_DTYPE = self.prev
 
 
 def rgbuv_hist(x: torch.Tensor, h: int = 64, insz: int = 128, method: str = "inverse-quadratic",
@@ -404,8 +422,8 @@ def rgbuv_hist(x: torch.Tensor, h: int = 64, insz: int = 128, method: str = "inv
                 dv = 1 / (1 + dv ** 2 / sigma ** 2)
             else:
                 raise Exception(f"Wrong kernel method {method}")
-            du = du.type(torch.float32)
-            dv = dv.type(torch.float32)
+            du = du.type(HIST_KERNEL_DTYPE)
+            dv = dv.type(HIST_KERNEL_DTYPE)
             per_ch.append(torch.mm((Iy * du).t(), dv))
         hists.append(torch.stack(per_ch))
     hists = torch.stack(hists)

@@ -149,34 +149,49 @@ def test_stylize_bf16_pipeline():
     assert rel_l2(out, ref_emul) < 1.5e-2
 
 
-def test_train_step_bf16_close_to_fp32():
-    """Training step in bf16 compute mode vs the fp32 HIP path: every loss within 3e-2 relative; the decoder
-    gradients of the content, style and variation terms aligned (cosine > 0.98).  The histogram term's gradient is
-    not compared: with random decoder weights ~96 % of the normalised decoded pixels sit outside the [0,1] clamp
-    of losses.py:170, the gradient mask is discontinuous there, and a bf16-sized perturbation of the decoded
-    image re-draws it (the fp32 test already needs 6e-2 for that term, tests/test_gpu_train.py)."""
+def test_train_step_bf16_against_same_rounding_oracle():
+    """Training step in bf16 compute mode against the ORACLE with the same operand rounding
+    (``R.conv_compute("bf16")``: every 3x3 conv rounds activations, weights and output gradients to bf16, fp32
+    accumulation -- the numerics csrc/conv3x3_bf16.hip implements), not against our own fp32 path.  Stated bf16
+    tolerance for the whole step: every loss within 2e-2 of the emulated oracle and within 3e-2 of the plain fp32
+    oracle; decoder gradients of the content, style and variation terms aligned with the emulated oracle's autograd
+    (cosine > 0.98; 19 + 12 convolutions deep a rounding-boundary flip moves whole bf16 ulps, see
+    test_stylize_bf16_pipeline).  The histogram term's gradient is not compared: with random decoder weights ~96 %
+    of the normalised decoded pixels sit outside the [0,1] clamp of losses.py:170 and a bf16-sized perturbation of
+    the decoded image re-draws the gradient mask (the fp32 test measures that term against a float64 arbiter)."""
     from style_transfer_amd import precision
     from test_gpu_train import _build
-    step, *_ = _build(False, [21], [2, 7, 14, 19, 25], 0.1)
+    cidx, sidx = [21], [2, 7, 14, 19, 25]
+    step, enc_sd, dec_sd, vgg_sd = _build(False, cidx, sidx, 0.1)
     g = torch.Generator().manual_seed(5)
-    content = torch.rand(2, 3, 64, 64, generator=g).cuda()
-    style = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    content = torch.rand(2, 3, 64, 64, generator=g)
+    style = torch.rand(2, 3, 64, 64, generator=g)
     params = list(step.decoder.named_parameters())
 
-    def run(i):
+    def oracle(i, emulate):
+        dec_ref = {k: v.clone().requires_grad_(True) for k, v in dec_sd.items()}
+        ce, se = torch.tensor([1e-5], requires_grad=True), torch.tensor([1e-5], requires_grad=True)
+        with R.conv_compute("bf16" if emulate else "f32"):
+            out = R.train_step_losses(content, style, enc_sd, dec_ref, vgg_sd, ce, se, 0.1, cidx, sidx,
+                                      1.0, 10.0, 1.0, 10.0, False)
+            if i is not None:
+                out[i].backward()
+        return [float(v.detach()) for v in out], {k: v.grad for k, v in dec_ref.items()}
+
+    l32, _ = oracle(None, False)
+    for i, name in enumerate(["content", "style", "variation"]):
+        lem, gem = oracle(i, True)
         for _, p in params + list(step.transformer.named_parameters()):
             p.grad = None
-        losses = step.forward_losses(content, style)
-        losses[i].backward()
-        return [float(l.detach()) for l in losses], [p.grad.clone() for _, p in params]
-
-    for i, name in enumerate(["content", "style", "variation"]):
-        l32, g32 = run(i)
         with precision.compute_dtype("bf16"):
-            l16, g16 = run(i)
-        for a, b in zip(l16, l32):
-            assert abs(a - b) <= 3e-2 * max(abs(b), 1e-3), name
-        for (pname, _), a, b in zip(params, g16, g32):
+            losses = step.forward_losses(content.cuda(), style.cuda())
+            losses[i].backward()
+        l16 = [float(l.detach()) for l in losses]
+        for a, b, c in zip(l16, lem, l32):
+            assert abs(a - b) <= 2e-2 * max(abs(b), 1e-3), (name, l16, lem)
+            assert abs(a - c) <= 3e-2 * max(abs(c), 1e-3), (name, l16, l32)
+        for pname, p in params:
+            a, b = p.grad.cpu(), gem[pname]               # named_parameters: "decoder.{idx}.weight" like the state dict
             assert torch.isfinite(a).all()
             if name == "variation" and pname.endswith("28.bias"):
                 continue                                     # analytically zero
