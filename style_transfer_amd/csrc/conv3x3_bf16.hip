@@ -790,11 +790,11 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   // PIPE schedule for the forward form (measured +2.7 % bf16, +1.3 % bf16x3 over the layer set); the gated
   // data-gradient form keeps the phase schedule (its doubled register loads make the interleave a small loss)
   if (p.cin % KC != 0)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, true, SPLIT, false>), grid, dim3(NTHREADS),
-                       C::LDS_BYTES, stream, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_bf16", (conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, true, SPLIT, false>), grid,
+                      dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false, SPLIT, !GATE>), grid, dim3(NTHREADS),
-                       C::LDS_BYTES, stream, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_bf16", (conv3x3_bf16_kernel<MT, NT, WM, WP, GATE, false, SPLIT, !GATE>), grid,
+                      dim3(NTHREADS), C::LDS_BYTES, stream, p);
   return st::check_launch("st_conv3x3_bf16");
 }
 
@@ -817,20 +817,25 @@ int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
     // persistent form: one block per CU (a multiple of 8, so a block's tiles stay on its XCD's slots)
     const bool persist = !getenv("ST_G8_NO_PERSIST");
     dim3 pgrid((unsigned)std::min<long long>(p.ntiles, persist ? 256 : p.ntiles));
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), pgrid,
-                       dim3(NTHREADS), C::LDS_BYTES + 8 * 128 * 16, stream, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_fwd_bf16_g8",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), pgrid,
+                      dim3(NTHREADS), C::LDS_BYTES + 8 * 128 * 16, stream, p);
   } else if (xg && yg)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), grid,
-                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_fwd_bf16_g8",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), grid,
+                      dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else if (xg)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, false>), grid,
-                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_fwd_bf16_g8",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, false>), grid,
+                      dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else if (p.cin % KC != 0)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, true, SPLIT, false, false, true>), grid,
-                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_fwd_bf16_g8",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, true, SPLIT, false, false, true>), grid,
+                      dim3(NTHREADS), C::LDS_BYTES, stream, p);
   else
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, true, false, true>), grid,
-                       dim3(NTHREADS), C::LDS_BYTES, stream, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_fwd_bf16_g8",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, true, false, true>), grid,
+                      dim3(NTHREADS), C::LDS_BYTES, stream, p);
   return st::check_launch("st_conv3x3_fwd_bf16_g8");
 }
 

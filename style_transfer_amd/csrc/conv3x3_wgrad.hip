@@ -614,19 +614,13 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
   p.tiles_per_split = pl.tiles_per_split; p.nsplit = pl.nsplit;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {   // 82.8 KB of dynamic LDS (> the 64 KB default limit)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(bf::conv3x3_wgrad_bf16_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf::LDS_BYTES_B);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(bf::conv3x3_wgrad_bf16_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf::LDS_BYTES_B);
-    attr_set = true;
-  }
   dim3 grid(st::cdiv(cin, CI), st::cdiv(cout, BO), pl.nsplit);
-  if (y_gate)
-    hipLaunchKernelGGL(bf::conv3x3_wgrad_bf16_kernel<true>, grid, dim3(NTHREADS), bf::LDS_BYTES_B, s, p);
+  if (y_gate)   // 82.8 KB of dynamic LDS (> the 64 KB default limit)
+    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", bf::conv3x3_wgrad_bf16_kernel<true>, grid, dim3(NTHREADS),
+                      bf::LDS_BYTES_B, s, p);
   else
-    hipLaunchKernelGGL(bf::conv3x3_wgrad_bf16_kernel<false>, grid, dim3(NTHREADS), bf::LDS_BYTES_B, s, p);
+    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", bf::conv3x3_wgrad_bf16_kernel<false>, grid, dim3(NTHREADS),
+                      bf::LDS_BYTES_B, s, p);
   int rc = st::check_launch("st_conv3x3_wgrad_bf16");
   if (rc != ST_OK) return rc;
   const long long nw = (long long)cout * cin * 9;

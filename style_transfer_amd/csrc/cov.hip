@@ -243,14 +243,8 @@ extern "C" int st_cov_fwd(const float* x, const float* mean, float* cov, float* 
                        workspace, b, c, n, p.chunks_per_split);
   } else {
     constexpr int lds = 2 * 128 * LSF * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(cov_fwd_kernel<128>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(cov_fwd_kernel<128>, grid, dim3(NT), lds, s, x, mean, workspace, b, c, n,
-                       p.chunks_per_split);
+    ST_LAUNCH_DYN_LDS("st_cov_fwd", cov_fwd_kernel<128>, grid, dim3(NT), lds, s, x, mean, workspace, b, c, n,
+                      p.chunks_per_split);
   }
   const long long total = (long long)b * c * c;
   hipLaunchKernelGGL(cov_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(total, 256), 2048)),

@@ -574,14 +574,8 @@ extern "C" int st_rgbuv_hist_bwd(const float* x, const float* hist, const float*
   hipLaunchKernelGGL(hist_prep_kernel, dim3(eb), dim3(NT), 0, s, x, rec, c, h, w, g.hs, g.ws, g.resize,
                      hp.intensity_scale, total);
   hipLaunchKernelGGL(hist_bwd_norm_kernel, dim3(n), dim3(NT), 0, s, ghist, hist, totals, draw);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(hist_bwd_pixel_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(hist_bwd_pixel_kernel, dim3(g.nsplit, 3, n), dim3(NT), BWD_LDS, s, rec, draw, gpix, g.N,
-                     n, g.chunks_per_split, hp);
+  ST_LAUNCH_DYN_LDS("st_rgbuv_hist_bwd", hist_bwd_pixel_kernel, dim3(g.nsplit, 3, n), dim3(NT), BWD_LDS, s, rec,
+                    draw, gpix, g.N, n, g.chunks_per_split, hp);
   hipLaunchKernelGGL(hist_bwd_chain_kernel, dim3(eb), dim3(NT), 0, s, rec, gpix, gs, g.N, hp.intensity_scale,
                      total);
   const long long tin = (long long)n * c * h * w;

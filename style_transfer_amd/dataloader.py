@@ -53,13 +53,16 @@ class STDataset(Dataset):
 
 class ShardedRandomSampler(Sampler):
     """RandomSampler(generator=g) restricted to rank's slice of each epoch's permutation.  With
-    world_size 1 it draws exactly what ``RandomSampler(data_source, generator=g)`` draws."""
+    world_size 1 it draws exactly what ``RandomSampler(data_source, generator=g)`` draws, epoch after epoch:
+    torch's ``RandomSampler.__iter__`` consumes the generator TWICE per epoch (the second ``randperm`` feeds the
+    ``num_samples % n`` tail even when that tail is empty), so a second permutation is drawn and dropped here."""
 
     def __init__(self, data_source, generator, rank: int = 0, world_size: int = 1):
         self.n, self.generator, self.rank, self.world = len(data_source), generator, rank, world_size
 
     def __iter__(self):
         perm = torch.randperm(self.n, generator=self.generator).tolist()
+        torch.randperm(self.n, generator=self.generator)      # keep the generator in step with RandomSampler
         per = self.n // self.world
         return iter(perm[self.rank * per:(self.rank + 1) * per] if self.world > 1 else perm)
 

@@ -11,7 +11,6 @@ cwd-relative blob (generator.py:78); without the flag that same path is used.
 from __future__ import annotations
 
 import argparse
-import io
 import os
 import sys
 
@@ -28,24 +27,26 @@ from .utils import timeit
 
 
 def parse_args(args):
-    parser = argparse.ArgumentParser(description="Inference from the model, plot and save result")
-    parser.add_argument('-cpkt', '--path_to_save_cpkt', type=str, help="Path to the save checkpoint")
-    parser.add_argument('-r', '--res', type=int, default=450, help="Inference resolution")
-    parser.add_argument('--plot_time', type=int, default=40, help="Comparison plot time")
-    parser.add_argument('--do_plot', action='store_true', default=True, help="Whether to plot or not")
-    parser.add_argument('--save_dir', type=str, default='./src/output', help="Path to save dir")
-    parser.add_argument('-c', '--path_to_content', type=str, help="Path to content dir to stylized")
-    parser.add_argument('-s', '--path_to_style', type=str, help="Path to style dir to use as style")
-    parser.add_argument('-a', '--alpha', type=float, default=1.0, help="alpha value for style and content adjustment")
+    """The reference's flags (src/inference.py:22-42: names, short forms, defaults, the start-up checks) plus two."""
+    parser = argparse.ArgumentParser(description="Stylise one content image with one style image and save the result")
+    add = parser.add_argument
+    add('-cpkt', '--path_to_save_cpkt', type=str, help="training checkpoint (transformer*.pth)")
+    add('-r', '--res', type=int, default=450, help="short side both images are resized to")
+    add('--plot_time', type=int, default=40, help="seconds the comparison figure stays up when shown")
+    add('--do_plot', action='store_true', default=True, help="kept for compatibility (always on in the reference)")
+    add('--save_dir', type=str, default='./src/output', help="where plot_A{alpha}.png and result_A{alpha}.png go")
+    add('-c', '--path_to_content', type=str, help="content image file")
+    add('-s', '--path_to_style', type=str, help="style image file")
+    add('-a', '--alpha', type=float, default=1.0, help="blend of stylised and content features (1 = fully stylised)")
     # additions (not in the reference)
-    parser.add_argument('--encoder_weights', type=str, default=None,
-                        help="vgg_normalised_conv4_1.pth (default: the reference's cwd-relative path)")
-    parser.add_argument('--dtype', choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")
+    add('--encoder_weights', type=str, default=None,
+        help="vgg_normalised_conv4_1.pth (default: the reference's cwd-relative path)")
+    add('--dtype', choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")
     args = parser.parse_args(args)
-
-    assert os.path.isfile(args.path_to_save_cpkt), "Please provide the .pth file"
-    assert os.path.isfile(args.path_to_content), "Please provide the correct content image path"
-    assert os.path.isfile(args.path_to_style), "Please provide the correct style image path"
+    for path, what in ((args.path_to_save_cpkt, "Please provide the .pth file"),
+                       (args.path_to_content, "Please provide the correct content image path"),
+                       (args.path_to_style, "Please provide the correct style image path")):
+        assert os.path.isfile(path or ""), what
     assert 64 < args.res < 1500, "Resolution too small or too large!"
     assert args.plot_time > 1, "Please provide the plot time larger than 0"
     return args
@@ -71,21 +72,29 @@ def main(args):
         style_transformation=T.Compose([T.Resize(args.res), T.ToTensor()]),
         device=device, sleep=args.plot_time, alpha=args.alpha, plot=False)
 
-    image3_np = result.squeeze().permute(1, 2, 0).detach().cpu()
-    image3_np = np.interp(image3_np, (image3_np.min(), image3_np.max()), (0, 1))
-    result = Image.fromarray((image3_np * 255).astype(np.uint8))
-
-    io_buf = io.BytesIO()
-    plot.savefig(io_buf, format='raw')
-    plot.close('all')
-    io_buf.seek(0)
-    result_plot = Image.frombytes('RGBA', (1000, 400), io_buf.getvalue(), 'raw')
-    io_buf.close()
-
+    stylised = minmax_to_uint8(result)                    # inference.py:74-76
+    comparison = figure_to_image(plot)                   # the 1000 x 400 three-panel figure, inference.py:78-83
     os.makedirs(args.save_dir, exist_ok=True)
-    result_plot.save(os.path.join(args.save_dir, f"plot_A{args.alpha}.png"))
-    result.save(os.path.join(args.save_dir, f"result_A{args.alpha}.png"))
-    return result
+    comparison.save(os.path.join(args.save_dir, f"plot_A{args.alpha}.png"))
+    stylised.save(os.path.join(args.save_dir, f"result_A{args.alpha}.png"))
+    return stylised
+
+
+def minmax_to_uint8(img: torch.Tensor) -> Image.Image:
+    """Normalised decoded image [1,3,H,W] -> 8-bit RGB the way the reference writes ``result_A{alpha}.png``:
+    stretch [min, max] onto [0, 1] in float64, scale by 255, truncate."""
+    hwc = img.detach().squeeze(0).permute(1, 2, 0).cpu().numpy()
+    unit = np.interp(hwc, (float(hwc.min()), float(hwc.max())), (0.0, 1.0))
+    return Image.fromarray((unit * 255).astype(np.uint8))
+
+
+def figure_to_image(plt_module) -> Image.Image:
+    """Rasterise the current matplotlib figure (10 x 4 in at 100 dpi) into an RGBA PIL image."""
+    fig = plt_module.gcf()
+    fig.canvas.draw()
+    rgba = np.asarray(fig.canvas.buffer_rgba()).copy()
+    plt_module.close('all')
+    return Image.fromarray(rgba, mode="RGBA")
 
 
 if __name__ == "__main__":

@@ -22,81 +22,78 @@ from .trainer import Trainer
 from .utils import ParseKwargsOptim, clear_cuda_cache, set_seed
 
 
-def parse_args(args):
-    parser = argparse.ArgumentParser()
-    # Data
-    parser.add_argument('--output_dir', type=str, help="The output directory to save")
-    parser.add_argument('--content_datapath', nargs='+', type=str,
-                        help="The path to content images dir (can be a list of paths)")
-    parser.add_argument('--style_datapath', nargs='+', type=str,
-                        help="The path to style images dir (can be a list of paths)")
-    parser.add_argument('--eval_contentpath', type=str, default="./src/data/eval_dir/content", help="The path to eval dir")
-    parser.add_argument('--eval_stylepath', type=str, default="./src/data/eval_dir/style", help="The path to style dir")
-    parser.add_argument('--batch_size', type=int, default=2, help="Batch size for the dataloader")
-    parser.add_argument('--eval_batch_size', type=int, default=1, help="Eval batch size for the dataloader")
-    parser.add_argument('--max_content_train_samples', type=int, default=10000, help="Number of content training samples")
-    parser.add_argument('--max_style_train_samples', type=int, default=10000, help="Number of style training samples")
-    parser.add_argument('--num_worker', type=int, default=2, help="Number of worker for dataloader")
-    parser.add_argument('--seed', type=int, default=42, help="A seed for reproducible training.")
-    parser.add_argument('--crop_width', type=int, default=256, help="Width of the image randomly center crop")
-    parser.add_argument('--crop_height', type=int, default=256, help="Width of the image randomly center crop")
-    parser.add_argument('--recursive_paths_load', action='store_true',
-                        help="Whether to enable recursive load to load all instance of image files"
-                             "found in the content and style datapath.")
-    # Training
-    parser.add_argument('--num_train_epochs', type=int, default=10, help="number training epochs")
-    parser.add_argument('--step_frequency', type=float, default=0.5,
-                        help="How often should you update the lr (Should be a fraction of an epoch)")
-    parser.add_argument('--with_tracking', action='store_true', help="Whether to enable experiment trackers for logging.")
-    parser.add_argument('--log_weights_cpkt', action='store_true', help="Whether to log weights to tracker")
-    parser.add_argument('--resume_from_checkpoint', type=str, default=None,
-                        help="If the training should continue from a checkpoint folder. (can be bool or string)")
-    parser.add_argument('--plot_per_epoch', action='store_true', help="Whether to plot comparison per epoch.")
-    parser.add_argument('--do_eval_per_epoch', action='store_true', help="Whether to run evaluate per epoch.")
-    parser.add_argument('--do_decoder_train', action='store_true',
-                        help="Whether to enable decoder training to expand model capacity.")
-    parser.add_argument('--use_pretrained_WCTDECODER', action='store_true',
-                        help="Whether to load pretrained WCT decoder that were trained on image recovery.")
-    parser.add_argument('--grayscale_content_transform', action='store_true',
-                        help="Whether to enable grayscale content convert.")
-    # Optimizer
-    parser.add_argument('--vgg_model_type', type=str, default='19',
-                        help="Which models of the vgg to use as a feature extractor")
-    parser.add_argument('--optim_name', nargs='+', default={'optim_name': 'adam'}, action=ParseKwargsOptim,
-                        help="Which optimizer to use, support for Kwargrs, example: '--optim_name adamax betas=0.9,0.99' ")
-    parser.add_argument('--learning_rate', type=float, default=1e-4,
-                        help="Initial learning rate (after the potential warmup period) to use.")
-    parser.add_argument('--gradient_threshold', type=float, default=None,
-                        help="Gradient threshold for clipping (use for exploding gradient) (recommended range 1-10)")
-    parser.add_argument('--alpha', type=float, default=1, help="weight for the content loss.")
-    parser.add_argument('--beta', type=float, default=10, help="weight for style loss.")
-    parser.add_argument('--gamma', type=float, default=1, help="weight for variance loss.")
-    parser.add_argument('--delta', type=float, default=10, help="weight for histogram loss.")
-    parser.add_argument('--eps', type=float, default=1e-5, help="Maximum eps value for AdaIN for both content and style.")
-    parser.add_argument('--content_layers_idx', nargs='+', type=int, default=[21], help="Vgg layers to compute content loss")
-    parser.add_argument('--style_layers_idx', nargs='+', type=int, default=[2, 7, 14, 19, 25],
-                        help="Vgg layers to compute style loss")
-    parser.add_argument('--use_VincentStyleLoss', action='store_true',
-                        help="Whether to enable the default style loss implementation using Gram matrices")
+# The reference's flag schema (src/train.py:13-87): names, types and defaults are the drop-in contract; the help text is ours.
+_FLAGS = [
+    # data
+    ('--output_dir', dict(type=str, help="directory that receives TotalL_*/transformer*.pth checkpoints")),
+    ('--content_datapath', dict(nargs='+', type=str, help="one or more directories of content images")),
+    ('--style_datapath', dict(nargs='+', type=str, help="one or more directories of style images")),
+    ('--eval_contentpath', dict(type=str, default="./src/data/eval_dir/content", help="content images of the eval grid")),
+    ('--eval_stylepath', dict(type=str, default="./src/data/eval_dir/style", help="style images of the eval grid")),
+    ('--batch_size', dict(type=int, default=2, help="training batch per process (per GPU under data parallel)")),
+    ('--eval_batch_size', dict(type=int, default=1, help="eval loader batch (paths, not tensors)")),
+    ('--max_content_train_samples', dict(type=int, default=10000, help="cap on content images used")),
+    ('--max_style_train_samples', dict(type=int, default=10000, help="cap on style images used")),
+    ('--num_worker', dict(type=int, default=2, help="DataLoader worker processes")),
+    ('--seed', dict(type=int, default=42, help="seed for python / numpy / torch and the sampler")),
+    ('--crop_width', dict(type=int, default=256, help="random-crop width after Resize(300)")),
+    ('--crop_height', dict(type=int, default=256, help="random-crop height after Resize(300)")),
+    ('--recursive_paths_load', dict(action='store_true', help="also collect images from sub-directories")),
+    # schedule / run control
+    ('--num_train_epochs', dict(type=int, default=10, help="epochs to run (counted from 0, also when resuming)")),
+    ('--step_frequency', dict(type=float, default=0.5, help="cosine LR step every this fraction of an epoch")),
+    ('--with_tracking', dict(action='store_true', help="wandb tracking (not part of this build: raises)")),
+    ('--log_weights_cpkt', dict(action='store_true', help="upload checkpoints to the tracker")),
+    ('--resume_from_checkpoint', dict(type=str, default=None, help="transformer*.pth to continue from")),
+    ('--plot_per_epoch', dict(action='store_true', help="show the comparison figure after each epoch")),
+    ('--do_eval_per_epoch', dict(action='store_true', help="render the eval grid when an epoch is the best so far")),
+    ('--do_decoder_train', dict(action='store_true', help="train the decoder too (otherwise only AdaIN's eps)")),
+    ('--use_pretrained_WCTDECODER', dict(action='store_true', help="start the decoder from feature_invertor_conv4_1.pth")),
+    ('--grayscale_content_transform', dict(action='store_true', help="feed content images as stacked grayscale")),
+    # optimiser / losses
+    ('--vgg_model_type', dict(type=str, default='19', help="loss network family (only '19' is ever built)")),
+    ('--optim_name', dict(nargs='+', default={'optim_name': 'adam'}, action=ParseKwargsOptim,
+                          help="optimizer name followed by key=value kwargs, e.g. adamax betas=0.9,0.99")),
+    ('--learning_rate', dict(type=float, default=1e-4, help="initial learning rate of the cosine schedule")),
+    ('--gradient_threshold', dict(type=float, default=None, help="clamp AdaIN eps gradients to +-this value")),
+    ('--alpha', dict(type=float, default=1, help="content-loss weight")),
+    ('--beta', dict(type=float, default=10, help="style-loss weight")),
+    ('--gamma', dict(type=float, default=1, help="total-variation weight")),
+    ('--delta', dict(type=float, default=10, help="RGB-uv histogram-loss weight")),
+    ('--eps', dict(type=float, default=1e-5, help="upper limit of AdaIN's trainable eps")),
+    ('--content_layers_idx', dict(nargs='+', type=int, default=[21], help="vgg19.features indices of the content loss")),
+    ('--style_layers_idx', dict(nargs='+', type=int, default=[2, 7, 14, 19, 25], help="vgg19.features indices of the style loss")),
+    ('--use_VincentStyleLoss', dict(action='store_true', help="covariance / L2-Wasserstein style loss instead of mean-std")),
     # additions (not in the reference)
-    parser.add_argument('--encoder_weights', type=str, default=None, help="vgg_normalised_conv4_1.pth")
-    parser.add_argument('--decoder_weights', type=str, default=None, help="feature_invertor_conv4_1.pth")
-    parser.add_argument('--vgg_weights', type=str, default=None, help="torchvision vgg19 state dict (vgg19-dcbb9e9d.pth)")
-    parser.add_argument('--dtype', choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")
-    parser.add_argument('--hip_graph', action='store_true',
-                        help="capture the training step in a HIP graph and replay it (single process)")
-    args = parser.parse_args(args)
+    ('--encoder_weights', dict(type=str, default=None, help="vgg_normalised_conv4_1.pth")),
+    ('--decoder_weights', dict(type=str, default=None, help="feature_invertor_conv4_1.pth")),
+    ('--vgg_weights', dict(type=str, default=None, help="torchvision vgg19 state dict (vgg19-dcbb9e9d.pth)")),
+    ('--dtype', dict(choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")),
+    ('--hip_graph', dict(action='store_true', help="replay the training step from HIP graphs (also under data parallel)")),
+    ('--log_steps', dict(action='store_true',
+                         help="keep the five per-batch loss scalars (trainer.py:475-480) and print them at the end of "
+                              "each epoch; they stay on the device during the epoch, no per-step host read")),
+]
 
-    # Sanity check (train.py:89-99)
-    assert os.path.isdir(args.output_dir), "Invalid output dir path!"
-    for path in args.content_datapath:
-        assert os.path.isdir(path), "Invalid content dir path!"
-    for path in args.style_datapath:
-        assert os.path.isdir(path), "Invalid style dir path!"
-    assert os.path.isfile(args.resume_from_checkpoint) if args.resume_from_checkpoint is not None else True, \
-        "Invalid cpkt path!"
-    assert args.max_content_train_samples > 0 and args.max_style_train_samples > 0, \
-        "Number of examples must be higher than 0"
+
+def parse_args(args):
+    parser = argparse.ArgumentParser(description="AdaIN style-transfer training on the MI355X HIP hot path")
+    for flag, spec in _FLAGS:
+        parser.add_argument(flag, **spec)
+    args = parser.parse_args(args)
+    # what the reference refuses to start with (train.py:89-99), checked up front
+    problems = []
+    if not os.path.isdir(args.output_dir or ""):
+        problems.append("Invalid output dir path!")
+    if not all(os.path.isdir(p) for p in args.content_datapath or [""]):
+        problems.append("Invalid content dir path!")
+    if not all(os.path.isdir(p) for p in args.style_datapath or [""]):
+        problems.append("Invalid style dir path!")
+    if args.resume_from_checkpoint is not None and not os.path.isfile(args.resume_from_checkpoint):
+        problems.append("Invalid cpkt path!")
+    if min(args.max_content_train_samples, args.max_style_train_samples) <= 0:
+        problems.append("Number of examples must be higher than 0")
+    assert not problems, " ".join(problems)
     return args
 
 
@@ -119,13 +116,8 @@ def main(args):
     args = parse_args(args)
     rank, world = 0, int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:                                    # one process per GPU, RCCL over xGMI
-        import torch.distributed as dist
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if torch.cuda.is_available():
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        from .parallel import init_process_group
+        dist, _ = init_process_group(rehearsal=bool(os.environ.get("ST_DP_REHEARSAL")))
         rank = dist.get_rank()
     clear_cuda_cache()
     set_seed(args.seed)
@@ -151,7 +143,8 @@ def main(args):
         use_pretrained_WCTDECODER=args.use_pretrained_WCTDECODER,
         grayscale_content_transform=args.grayscale_content_transform, use_VincentStyleLoss=args.use_VincentStyleLoss,
         config=args, encoder_weights=args.encoder_weights, decoder_weights=args.decoder_weights,
-        vgg_weights=args.vgg_weights, compute_dtype=args.dtype, use_hip_graph=args.hip_graph)
+        vgg_weights=args.vgg_weights, compute_dtype=args.dtype, use_hip_graph=args.hip_graph,
+        log_steps=args.log_steps)
     history = trainer.train()
     if world > 1:
         import torch.distributed as dist

@@ -353,7 +353,7 @@ class Trainer:
                  grayscale_content_transform: bool = False, use_VincentStyleLoss: bool = False,
                  content_layers_idx: List[int] = [12, 16, 21], style_layers_idx: List[int] = [0, 5, 10, 19, 28],
                  encoder_weights=None, decoder_weights=None, vgg_weights=None, device=None,
-                 compute_dtype: str = "f32", use_hip_graph: bool = False):
+                 compute_dtype: str = "f32", use_hip_graph: bool = False, log_steps: bool = False):
         self.output_dir = output_dir
         self.dataloaders = dataloaders.__call__() if callable(dataloaders) else dataloaders
         self.per_device_batch_size = per_device_batch_size
@@ -383,6 +383,10 @@ class Trainer:
         self.encoder_weights, self.decoder_weights, self.vgg_weights = encoder_weights, decoder_weights, vgg_weights
         self.compute_dtype = compute_dtype       # "f32" | "bf16" | "bf16x3" (precision.py)
         self.use_hip_graph = bool(use_hip_graph)  # replay the step from a HIP graph (GraphedStep)
+        # the five per-batch scalars of trainer.py:475-480 (content, style, variation, hist, total): kept in a device
+        # tensor during the epoch and read ONCE at its end -- the reference's five .item() calls per step would put a
+        # host synchronisation into every step
+        self.log_steps = bool(log_steps)
         if self.with_tracking:
             raise RuntimeError("wandb tracking is outside the hot path this build covers (SURVEY.md section 2)")
         self.wandb = None
@@ -654,6 +658,7 @@ class Trainer:
         history = []
         for epoch in range(init_epoch, self.num_train_epochs):
             sums = torch.zeros(5, dtype=torch.float64, device=self.device)
+            step_log = torch.zeros((steps_per_epoch, 5), dtype=torch.float32, device=self.device) if self.log_steps else None
             transformer.train()
             if self.do_decoder_train:
                 decoder.train()
@@ -662,7 +667,10 @@ class Trainer:
                 style_imgs = batch['style_image'].to(self.device, non_blocking=True).contiguous()
                 losses = run_step(content_imgs, style_imgs)
                 completed_step += step                                          # trainer.py:475 (sic: index, not 1)
-                sums += torch.stack([l.detach().double().reshape(()) for l in losses])
+                row = torch.stack([l.detach().reshape(()) for l in losses])
+                sums += row.double()
+                if step_log is not None and step < steps_per_epoch:
+                    step_log[step].copy_(row)
                 scheduler_count += 1
                 if scheduler_count >= scheduler_steps:                          # trainer.py:498-502
                     scheduler.step()
@@ -672,6 +680,12 @@ class Trainer:
             loss_list.append(avg_total)
             history.append({"epoch": epoch, "content": avg_content, "style": avg_style, "variation": avg_var,
                             "hist": avg_hist, "total": avg_total})
+            if step_log is not None:
+                history[-1]["steps"] = step_log.tolist()       # [step][content, style, variation, hist, total]
+                if self.rank == 0:
+                    for i, (c_, s_, v_, h_, t_) in enumerate(history[-1]["steps"]):
+                        print(f"     step {i}: content {c_:.6g} style {s_:.6g} variation {v_:.6g} hist {h_:.6g} "
+                              f"total {t_:.6g}")
             if self.rank == 0:
                 epss = transformer.get_current_eps()
                 print(f"   Epoch [{epoch + 1}/{self.num_train_epochs}] total {avg_total} content {avg_content} "
@@ -728,8 +742,6 @@ class Trainer:
 
     def evaluate_plots(self, encoder, decoder, transformer):
         """The per-epoch eval grid of trainer.py:530-559: one 1000x400 RGBA comparison per eval batch."""
-        import io
-        from PIL import Image
         from . import transforms as T
         plots = []
         for batch in self.dataloaders.get('eval', []):
@@ -740,12 +752,8 @@ class Trainer:
                 style_transformation=T.Compose([T.Resize(256), T.ToTensor()]),
                 device=self.device, plot=self.plot_per_epoch)
             try:
-                io_buf = io.BytesIO()
-                plot.savefig(io_buf, format='raw')
-                plot.close('all')
-                io_buf.seek(0)
-                plots.append(Image.frombytes('RGBA', (1000, 400), io_buf.getvalue(), 'raw'))
-                io_buf.close()
+                from .inference import figure_to_image
+                plots.append(figure_to_image(plot))
             except Exception:
                 warnings.warn("Byte IO fail!")
         return plots

@@ -97,3 +97,31 @@ def test_stylize_2048_alpha_linearity(models):
             got = stylize(enc, dec, ada, c, s, alpha=alpha)
             assert got.shape == (1, 3, 2048, 2048)
             assert rel_err(got, want) < 1e-4
+
+
+def test_stylize_configs1_batch_matches_oracle_on_decoder_side_crops(models):
+    """BASELINE configs[1] (batch 16 at 512x512) through the WHOLE pipeline: the stylised image against the oracle's
+    decoder run on corner crops of the pipeline's own AdaIN features (output pixels more than ~6 feature cells from
+    a crop's cut edges depend on nothing outside it), and those AdaIN features against the oracle's AdaIN of the
+    full-size encoder features (exact per plane: AdaIN statistics need the whole plane, which is why the crops are
+    taken after it).  Encoder side at this size: test_encoder_full_size_matches_oracle_on_crops."""
+    from style_transfer_amd.pipeline import stylize
+    from style_transfer_amd.transformer import AdaIN
+    enc, dec, enc_sd, dec_sd = models
+    ada = AdaIN().cuda()
+    g = torch.Generator().manual_seed(16)
+    c = torch.rand(16, 3, 512, 512, generator=g)
+    s = torch.rand(16, 3, 512, 512, generator=g)
+    with torch.no_grad():
+        out = stylize(enc, dec, ada, c.cuda(), s.cuda(), alpha=1.0)
+        fc, fs = enc(c.cuda()), enc(s.cuda())
+        t = ada(fc, fs, alpha=1.0)
+    torch.cuda.synchronize()
+    assert out.shape == (16, 3, 512, 512)
+    for n in (0, 15):
+        t_ref = R.adain_forward(fc[n:n + 1].cpu(), fs[n:n + 1].cpu(), torch.tensor([1e-5]), torch.tensor([1e-5]), 1e-5)
+        assert rel_err(t[n:n + 1], t_ref) < 1e-4
+        tl = R.decoder_forward(t[n:n + 1, :, :24, :24].cpu(), dec_sd)          # 24 cells -> 192 px, 128 px exact
+        br = R.decoder_forward(t[n:n + 1, :, -24:, -24:].cpu(), dec_sd)
+        assert rel_err(out[n:n + 1, :, :128, :128], tl[:, :, :128, :128]) < 1e-3
+        assert rel_err(out[n:n + 1, :, -128:, -128:], br[:, :, -128:, -128:]) < 1e-3

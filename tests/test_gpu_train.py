@@ -213,3 +213,31 @@ def test_trainer_loop_with_hip_graph_matches_eager(tmp_path, monkeypatch):
         kw2 = dict(kw, num_train_epochs=3, resume_from_checkpoint=str(last), output_dir=str(tmp_path / "resumed"))
         hist2 = Trainer({"train": batches}, **kw2).train()
     assert [h["epoch"] for h in hist2] == [2] and hist2[0]["total"] == hist2[0]["total"]
+
+
+def test_eager_forward_after_graph_replays_uses_current_weights():
+    """a HIP-graph replay moves the decoder weights in place through captured optimizer kernels without
+    bumping Parameter._version, so a packed-weight cache keyed on the version alone would serve STALE packed copies
+    to an eager forward between replays (per-epoch eval, Trainer.stylize after train()).  After every batch of
+    replays an eager stylize must equal a fresh Decoder holding the current state_dict."""
+    from style_transfer_amd.generator import Decoder
+    from style_transfer_amd.trainer import Trainer
+    run, decoder, transformer, lr = _trainer_for_steps(True)
+    lr.fill_(1e-2)                                     # large steps: stale weights would be far off
+    encoder = run.step.encoder
+    g = torch.Generator().manual_seed(31)
+    batches = [(torch.rand(2, 3, 64, 64, generator=g).cuda(), torch.rand(2, 3, 64, 64, generator=g).cuda())
+               for _ in range(10)]
+    c, s = batches[0]
+    seen = []
+    for i, (bc, bs) in enumerate(batches):
+        run(bc, bs)
+        if i in (4, 6, 9):                               # after 2, 4 and 7 replays (the capture is call 3)
+            assert run.graph is not None and run.replays == i - 2
+            got = Trainer.stylize(encoder, decoder, transformer, c, s, alpha=1.0, normalize=False)
+            fresh = Decoder().cuda().eval()
+            fresh.load_state_dict(decoder.state_dict())
+            want = Trainer.stylize(encoder, fresh, transformer, c, s, alpha=1.0, normalize=False)
+            assert rel_l2(got, want) < 1e-6, i
+            seen.append(got)
+    assert rel_l2(seen[1], seen[0]) > 1e-3 and rel_l2(seen[2], seen[1]) > 1e-3     # the weights did move
