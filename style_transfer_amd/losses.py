@@ -319,14 +319,28 @@ class _MomentsFunction(torch.autograd.Function):
 
 
 class VincentStyleLoss(nn.Module):
-    """losses.py:42-90.  The covariance (the O(C^2 HW) "Gram" term) and its gradient are MFMA
-    kernels; the C x C eigendecompositions and products of ``l2wass_dist`` stay on
-    ``torch.linalg.eigh`` / ``torch.matmul`` (rocSOLVER / rocBLAS), as SURVEY.md K7b records."""
+    """losses.py:42-90.  The covariance (the O(C^2 HW) "Gram" term) and its gradient are MFMA kernels
+    (csrc/cov.hip); the C x C eigendecompositions of ``l2wass_dist`` are rocSOLVER's syevd -- the driver
+    ``torch.linalg.eigh`` uses -- called directly (``eigh.syevd``: no per-call host read of ``info``), the C x C
+    products stay on ``torch.matmul`` (rocBLAS), as SURVEY.md K7b records.
+
+    ``forward(input, target)`` is the reference's per-layer call.  A training step has five style layers and the
+    decompositions are latency-bound (11.5 ms for [8, 512, 512], 13.0 ms for [16, 512, 512]), so the step engine
+    uses the two-stage form instead:
+
+    * ``prepare_targets(target_feats)`` -- everything that depends on the STYLE image only (mean, covariance,
+      ``eigh(cov_stl)``, ``root_cov_stl``, its trace), layers with equal channel counts batched into one
+      decomposition, each group on its own side stream: issued right after the style image's loss-VGG pass, it
+      overlaps the encoder / decoder / loss-VGG convolutions that follow;
+    * ``forward_multi(input_feats, prepared)`` -- the stylised side: covariances on the main stream, then
+      ``root @ cov @ root`` and its eigenvalues per group, again concurrently.
+    Same arithmetic per layer as ``forward``; the sum over layers is what trainer.py:257-263 computes."""
 
     def __init__(self, scale_factor=1e-5):
         super().__init__()
         warnings.warn("\n Using VincentStyleLoss might me slow!")
         self.scale_factor = scale_factor
+        self._streams = {}
 
     @staticmethod
     def calc_2_moments(x):
@@ -336,26 +350,129 @@ class VincentStyleLoss(nn.Module):
     def matrix_diag(diagonal):
         return torch.diag_embed(diagonal)
 
-    def l2wass_dist(self, mean_stl, cov_stl, mean_synth, cov_synth):
-        eigvals, eigvects = torch.linalg.eigh(cov_stl)
-        eigroot_mat = self.matrix_diag(torch.sqrt(eigvals.clip(0)))
-        root_cov_stl = torch.matmul(torch.matmul(eigvects, eigroot_mat), torch.transpose(eigvects, -1, -2))
-        tr_cov_stl = torch.sum(eigvals.clip(0), dim=1, keepdim=True)
+    # ---- pieces of l2wass_dist (losses.py:67-81) ------------------------------------------------------
+    #: how ``root_cov_stl = cov_stl^(1/2)`` (losses.py:69-71) is evaluated.  "eigh": the reference's route, V sqrt(clip(L,
+    #: 0)) V^T from an eigendecomposition (rocSOLVER: 13 ms for the two 512-channel layers of a batch of 8, a chain of
+    #: ~2000 dependent tiny launches).  "newton-schulz" (default): the same matrix function by the coupled
+    #: Newton-Schulz iteration -- 3 batched C x C GEMMs per iteration on the matrix pipe, no eigendecomposition;
+    #: measured on the loss-VGG features of the BASELINE configs[2] step it is as close to the float64 result as the
+    #: fp32 eigh route is (both 1e-5 .. 4e-4 of the layer's distance; tests/test_gpu_backward.py checks both routes
+    #: against the reference's golden vectors).  No gradient flows through this side (style image only).
+    #: The iteration is used only when the layer has more pixels than channels (H*W > C: every BASELINE config; a
+    #: covariance of fewer samples than channels is rank-deficient by construction, and on an exactly singular input
+    #: the iteration's null directions are decided by rounding noise) -- otherwise the eigh route runs.  16
+    #: iterations: eigen-directions down to 1e-6 of the norm have converged, and a rounding-NEGATIVE eigenvalue of
+    #: the PSD input (|.| <= 1e-6 of the norm in fp32) cannot leave the iteration's basin within that many steps.
+    STYLE_ROOT = "newton-schulz"
+    NS_ITERS = 16
+
+    @classmethod
+    def _style_side(cls, cov_stl, n_pixels=None):
+        """(root_cov_stl, tr_cov_stl) of losses.py:69-72.  ``n_pixels``: H*W of the feature map behind ``cov_stl``."""
+        if cls.STYLE_ROOT == "eigh" or n_pixels is None or n_pixels <= cov_stl.shape[-1]:
+            from . import eigh
+            eigvals, eigvects = eigh.syevd(cov_stl)
+            pos = eigvals.clip(0)
+            root_cov_stl = torch.matmul(eigvects * torch.sqrt(pos).unsqueeze(-2), torch.transpose(eigvects, -1, -2))
+            return root_cov_stl, torch.sum(pos, dim=1, keepdim=True)
+        # cov_stl = (x - mu)(x - mu)^T is positive semi-definite: sum(clip(eigenvalues, 0)) is its trace (the argument
+        # of _synth_side for tr_cov_synth), and V sqrt(clip(L, 0)) V^T is its principal square root.
+        tr_cov_stl = torch.diagonal(cov_stl, dim1=-2, dim2=-1).sum(dim=1, keepdim=True)
+        n = cov_stl.shape[-1]
+        eye = torch.eye(n, dtype=cov_stl.dtype, device=cov_stl.device).expand_as(cov_stl)
+        norm = cov_stl.flatten(1).norm(dim=1).clamp_min(1e-30).view(-1, 1, 1)      # Frobenius >= spectral norm
+        y = cov_stl / norm                                                          # spectrum in [0, 1]
+        z = eye
+        eye15 = 1.5 * eye
+        for _ in range(cls.NS_ITERS):                     # Y -> A^(1/2), Z -> A^(-1/2)
+            t = torch.baddbmm(eye15, z, y, beta=1.0, alpha=-0.5)
+            y, z = torch.bmm(y, t), torch.bmm(t, z)
+        return y * torch.sqrt(norm), tr_cov_stl
+
+    @staticmethod
+    def _synth_side(root_cov_stl, tr_cov_stl, cov_synth):
+        """tr_cov_stl + tr_cov_synth - 2 var_overlap per matrix (losses.py:73-80 without the mean term)."""
+        from . import eigh
         # losses.py:73 sums eigvalsh(cov_synth).clip(0).  cov_synth = (x - mu)(x - mu)^T is positive semi-definite by
         # construction, so that sum IS its trace up to fp32 eigenvalue rounding (<= C * 1e-7 relative, the slightly
         # negative computed eigenvalues the clip removes); its gradient, the projector onto range(cov_synth), acts
         # on x - mu exactly like the identity.  Taking the trace saves one of the three batched
-        # eigendecompositions per layer (rocSOLVER: 12 ms for [8, 512, 512]).
+        # eigendecompositions per layer.
         tr_cov_synth = torch.diagonal(cov_synth, dim1=-2, dim2=-1).sum(dim=1, keepdim=True)
-        mean_diff_squared = torch.mean((mean_synth - mean_stl) ** 2)
         cov_prod = torch.matmul(torch.matmul(root_cov_stl, cov_synth), root_cov_stl)
-        var_overlap = torch.sum(torch.sqrt(torch.linalg.eigvalsh(cov_prod).clip(0.1)), dim=1, keepdim=True)
-        dist = mean_diff_squared + tr_cov_stl + tr_cov_synth - 2 * var_overlap
-        return dist
+        var_overlap = torch.sum(torch.sqrt(eigh.eigvalsh(cov_prod).clip(0.1)), dim=1, keepdim=True)
+        return tr_cov_stl + tr_cov_synth - 2 * var_overlap
+
+    def l2wass_dist(self, mean_stl, cov_stl, mean_synth, cov_synth, n_pixels=None):
+        root_cov_stl, tr_cov_stl = self._style_side(cov_stl, n_pixels)
+        mean_diff_squared = torch.mean((mean_synth - mean_stl) ** 2)
+        return mean_diff_squared + self._synth_side(root_cov_stl, tr_cov_stl, cov_synth)
 
     def forward(self, input_f, target_f):
         mean_synth, cov_synth = self.calc_2_moments(input_f)
         with torch.no_grad():
             mean_stl, cov_stl = self.calc_2_moments(target_f)
-        loss = self.l2wass_dist(mean_stl, cov_stl, mean_synth, cov_synth)
+        loss = self.l2wass_dist(mean_stl, cov_stl, mean_synth, cov_synth, int(target_f.shape[2] * target_f.shape[3]))
         return loss.mean() * self.scale_factor
+
+    # ---- the step engine's form: layers grouped by channel count, groups on side streams ---------------
+    def _side_stream(self, key):
+        dev = torch.cuda.current_device()
+        st = self._streams.get((dev, key))
+        if st is None:
+            st = self._streams[(dev, key)] = torch.cuda.Stream()
+        return st
+
+    @staticmethod
+    def _groups(feats):
+        groups = {}
+        for i, f in enumerate(feats):
+            groups.setdefault(int(f.shape[1]), []).append(i)
+        return sorted(groups.items(), key=lambda kv: -kv[0])          # widest (slowest) group first
+
+    @torch.no_grad()
+    def prepare_targets(self, target_feats):
+        """Style-image side of every layer; returns an opaque list for ``forward_multi``.  Work is issued on side
+        streams and NOT waited for here."""
+        cur = torch.cuda.current_stream()
+        prepared = []
+        for c, idxs in self._groups(target_feats):
+            st = self._side_stream(("stl", c))
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                moments = [self.calc_2_moments(target_feats[i]) for i in idxs]
+                mean_stl = [m for m, _ in moments]
+                # layers of one group may differ in H*W (relu4_1 / conv4_4 do not): the smallest decides the route
+                n_pixels = min(int(target_feats[i].shape[2] * target_feats[i].shape[3]) for i in idxs)
+                root, tr = self._style_side(torch.cat([cv for _, cv in moments]), n_pixels)
+            for i in idxs:
+                target_feats[i].record_stream(st)
+            prepared.append((c, idxs, mean_stl, root, tr, st))
+        return prepared
+
+    def forward_multi(self, input_feats, prepared):
+        """Sum over the layers of ``forward(input_feats[i], target_i)`` given ``prepare_targets(targets)``."""
+        cur = torch.cuda.current_stream()
+        moments = [self.calc_2_moments(f) for f in input_feats]          # MFMA covariances, main stream
+        parts = []
+        for c, idxs, mean_stl, root, tr, st_stl in prepared:
+            st = self._side_stream(("syn", c))
+            st.wait_stream(cur)
+            st.wait_stream(st_stl)
+            nb = int(input_feats[idxs[0]].shape[0])
+            with torch.cuda.stream(st):
+                cov_synth = torch.cat([moments[i][1] for i in idxs]) if len(idxs) > 1 else moments[idxs[0]][1]
+                # the mean term is per layer (a scalar over the layer's whole batch, losses.py:75)
+                mds = [((moments[i][0] - m) ** 2).mean() for i, m in zip(idxs, mean_stl)]
+                rest = self._synth_side(root, tr, cov_synth)
+                for k in range(len(idxs)):
+                    dist = mds[k] + rest[k * nb:(k + 1) * nb]
+                    parts.append((dist.mean() * self.scale_factor, st))
+            for t in (root, tr, *mean_stl, *(moments[i][k] for i in idxs for k in (0, 1))):
+                t.record_stream(st)
+        total = None
+        for val, st in parts:
+            cur.wait_stream(st)
+            val.record_stream(cur)
+            total = val if total is None else total + val
+        return total

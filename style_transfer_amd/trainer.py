@@ -157,11 +157,16 @@ class StyleTransferStep:
         self.hist_loss = HistLoss()
         self.norm = Normalize(IMAGENET_MEAN, IMAGENET_STD)
 
-    def partial_losses(self, content_features, style_features, stylized_outputs, style_imgs, content_imgs):
+    def partial_losses(self, content_features, style_features, stylized_outputs, style_imgs, content_imgs,
+                       prepared_style=None):
         """First stage of Trainer.compute_loss: (content, style, variation, q[2]) where q = the local sums under
-        the sqrt of the two Hellinger terms (stylised vs style, stylised vs content)."""
+        the sqrt of the two Hellinger terms (stylised vs style, stylised vs content).  ``prepared_style``: the
+        style-image side of VincentStyleLoss computed ahead (``prepare_targets``, side streams)."""
         loss_content = sum(self.content_loss(f['model_output'], f['orginal']) for f in content_features)
-        loss_style = sum(self.style_loss(f['model_output'], f['orginal']) for f in style_features)
+        if prepared_style is not None:
+            loss_style = self.style_loss.forward_multi([f['model_output'] for f in style_features], prepared_style)
+        else:
+            loss_style = sum(self.style_loss(f['model_output'], f['orginal']) for f in style_features)
         variation_loss = self.variation_loss(stylized_outputs)
         blk = self.hist_loss.histogram_block
         stylized_hist = blk(stylized_outputs)             # computed once, used by both terms
@@ -187,6 +192,14 @@ class StyleTransferStep:
         return self.combine(partials, allreduce_q(partials[3]), batch)
 
     def forward_partials(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor):
+        # The style image's loss-VGG pass goes FIRST: with VincentStyleLoss everything that depends on the style
+        # image alone (covariances, eigh(cov_stl), root_cov_stl) is then issued on side streams and overlaps the
+        # encoder / decoder / loss-VGG convolutions below.  Same values as the reference's order (trainer.py:453).
+        style_n = self.norm(style_imgs)
+        with torch.no_grad():
+            org_style = self.loss_vgg.forward_multi(style_n, [self.style_layers_idx])[0]
+        prepared_style = self.style_loss.prepare_targets(org_style) if hasattr(self.style_loss, "prepare_targets") \
+            else None
         with torch.no_grad():                              # frozen encoder: forward only
             if content_imgs.shape == style_imgs.shape:
                 # one pass over [content; style]: same kernels, same per-image results (no cross-image op in
@@ -199,16 +212,15 @@ class StyleTransferStep:
                 encode_Sfeatures = self.encoder(style_imgs)
         transformed_features = self.transformer(encode_Cfeatures, encode_Sfeatures, alpha=1.0)   # trainer.py:433-434
         decode_imgs = self.decoder(transformed_features)
-        content_n, style_n = self.norm(content_imgs), self.norm(style_imgs)
+        content_n = self.norm(content_imgs)
         decode_n = self.norm(decode_imgs)
         with torch.no_grad():
             org_content = self.loss_vgg.forward_multi(content_n, [self.content_layers_idx])[0]
-            org_style = self.loss_vgg.forward_multi(style_n, [self.style_layers_idx])[0]
         gen_content, gen_style = self.loss_vgg.forward_multi(decode_n, [self.content_layers_idx, self.style_layers_idx])
         # the reference indexes the getter's layer-ordered outputs by position (trainer.py:448-457)
         content_features = [{"orginal": o, "model_output": g} for o, g in zip(org_content, gen_content)]
         style_features = [{"orginal": o, "model_output": g} for o, g in zip(org_style, gen_style)]
-        return self.partial_losses(content_features, style_features, decode_n, style_n, content_n)
+        return self.partial_losses(content_features, style_features, decode_n, style_n, content_n, prepared_style)
 
     def forward_losses(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, global_batch: Optional[int] = None):
         partials = self.forward_partials(content_imgs, style_imgs)
@@ -675,6 +687,9 @@ class Trainer:
                 if scheduler_count >= scheduler_steps:                          # trainer.py:498-502
                     scheduler.step()
                     scheduler_count = 0
+            if self.use_VincentStyleLoss:
+                from . import eigh
+                eigh.check()                                                     # solver `info` of the whole epoch
             avg = (sums / steps_per_epoch).tolist()                              # one device->host read per epoch
             avg_content, avg_style, avg_var, avg_hist, avg_total = avg
             loss_list.append(avg_total)

@@ -11,6 +11,11 @@ from oracle import ref_ops as R
 pytestmark = pytest.mark.gpu
 
 
+def rel_l2(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
 def rel_err(a, b):
     a = a.detach().double().cpu(); b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
@@ -198,9 +203,13 @@ def test_covariance_fwd_bwd(b, c, h, w):
     assert rel_err(xg.grad, xr.grad) < 1e-4
 
 
-def test_vincent_loss_golden(golden_dir):
+@pytest.mark.parametrize("route", ["newton-schulz", "eigh"])
+def test_vincent_loss_golden(golden_dir, route, monkeypatch):
+    """VincentStyleLoss against the reference's golden value and gradient, for both ways of forming root_cov_stl
+    (the default Newton-Schulz iteration and the reference's eigh route)."""
     import warnings
     from style_transfer_amd.losses import VincentStyleLoss
+    monkeypatch.setattr(VincentStyleLoss, "STYLE_ROOT", route)
     g = np.load(os.path.join(golden_dir, "losses.npz"))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -212,6 +221,32 @@ def test_vincent_loss_golden(golden_dir):
     assert rel_err(cov, torch.from_numpy(g["vincent_cov"])) < 1e-4
     assert float(v) == pytest.approx(float(g["vincent"]), rel=1e-3)
     assert rel_err(a.grad, torch.from_numpy(g["vincent_da"])) < 1e-2     # eigh backward on another LAPACK
+
+
+def test_vincent_multi_layer_form_equals_per_layer_calls():
+    """prepare_targets / forward_multi (layers grouped by channel count, one batched decomposition per group, groups on
+    side streams: what the training step uses) == the sum of the reference-shaped per-layer forward(input, target)
+    calls, values and input gradients, on five layers shaped like the CLI's style layers."""
+    import warnings
+    from style_transfer_amd.losses import VincentStyleLoss
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vin = VincentStyleLoss()
+    g = torch.Generator().manual_seed(77)
+    shapes = [(2, 64, 24, 24), (2, 128, 12, 12), (2, 256, 12, 12), (2, 512, 24, 24), (2, 512, 24, 24)]
+    ins = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    tgts = [(torch.randn(s, generator=g) * 1.3 + 0.2).cuda() for s in shapes]
+    one = sum(vin(i, t) for i, t in zip(ins, tgts))
+    one.backward()
+    g_one = [i.grad.clone() for i in ins]
+    for i in ins:
+        i.grad = None
+    multi = vin.forward_multi(ins, vin.prepare_targets(tgts))
+    multi.backward()
+    torch.cuda.synchronize()
+    assert float(multi) == pytest.approx(float(one), rel=1e-5)
+    for a, b in zip(g_one, ins):
+        assert rel_l2(b.grad, a) < 1e-4
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16"])

@@ -1,0 +1,76 @@
+"""Batched symmetric eigendecomposition used by VincentStyleLoss.l2wass_dist (losses.py:69, 73, 78): the hand-written
+LDS-resident Jacobi kernel for C <= 128 and the direct rocSOLVER binding for larger C, against torch.linalg.eigh in
+float64 on the CPU (eigenvalues, reconstruction, orthogonality) and its autograd (eigvalsh backward)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sym(b, c, kind, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "cov":                                   # (x - mu)(x - mu)^T with a spread of channel scales: PSD, ill-conditioned
+        x = torch.randn(b, c, 4 * c, generator=g) * torch.logspace(-2, 1, c).view(1, c, 1)
+        x = x - x.mean(-1, keepdim=True)
+        return x @ x.transpose(-1, -2)
+    if kind == "rank":                                  # fewer samples than channels: rank-deficient
+        x = torch.randn(b, c, max(2, c // 4), generator=g)
+        return x @ x.transpose(-1, -2)
+    if kind == "diag":
+        return torch.diag_embed(torch.randn(b, c, generator=g))
+    a = torch.randn(b, c, c, generator=g)               # indefinite
+    return a + a.transpose(-1, -2)
+
+
+@pytest.mark.parametrize("c", [2, 6, 64, 100, 128, 256])
+@pytest.mark.parametrize("kind", ["cov", "rank", "diag", "indefinite"])
+def test_eigh_matches_float64(c, kind):
+    from style_transfer_amd import eigh
+    a = _sym(3, c, kind, 100 + c)
+    # C <= 128: the Jacobi kernel (the trainer routes C <= eigh.SMALL_MAX to it); larger: rocSOLVER's syevd
+    w, v = eigh.syevj_small(a.cuda()) if c <= 128 else eigh.syevd(a.cuda())
+    eigh.check()                                        # converged (sweeps < max / info == 0)
+    w, v = w.cpu().double(), v.cpu().double()
+    ref = torch.linalg.eigvalsh(a.double())
+    scale = ref.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    assert float(((w - ref).abs() / scale).max()) < 5e-5                       # eigenvalues, ascending
+    assert bool((w[:, 1:] >= w[:, :-1]).all())
+    recon = v @ torch.diag_embed(w) @ v.transpose(-1, -2)
+    assert float((recon - a.double()).abs().max() / a.abs().max()) < 1e-4      # a = V diag(w) V^T
+    eye = torch.eye(c, dtype=torch.float64)
+    assert float((v.transpose(-1, -2) @ v - eye).abs().max()) < 1e-4           # orthonormal columns
+
+
+@pytest.mark.parametrize("c", [64, 128, 256])
+def test_eigvalsh_backward_matches_torch_autograd(c):
+    """d/dA sum f(lambda) through the custom Function == torch.linalg.eigvalsh's autograd (float64, CPU)."""
+    from style_transfer_amd import eigh
+    a = _sym(2, c, "cov", 7 + c)
+    a_dev = a.cuda().requires_grad_(True)
+    lam = eigh.eigvalsh(a_dev)
+    # a smooth stand-in for the sqrt(clip(., 0.1)) of losses.py:78-79: the clip's kink would turn an eigenvalue that
+    # lands on either side of it in fp32 / float64 into an O(1) gradient difference
+    torch.sqrt(lam * lam * 1e-4 + 1.0).sum().backward()
+    a64 = a.double().requires_grad_(True)
+    lam64 = torch.linalg.eigvalsh(a64)
+    torch.sqrt(lam64 * lam64 * 1e-4 + 1.0).sum().backward()
+    g, ref = a_dev.grad.cpu().double(), a64.grad
+    ref = 0.5 * (ref + ref.transpose(-1, -2))
+    assert float((g - ref).norm() / ref.norm()) < 1e-3      # fp32 eigenvectors of an ill-conditioned matrix
+
+
+def test_small_eigh_timing_report():
+    """Not a pass/fail bar: prints what the hand-written kernel costs next to rocSOLVER at the style-layer shapes."""
+    import time
+    from style_transfer_amd import eigh
+    for c in (64, 128):
+        a = _sym(8, c, "cov", c).cuda()
+        for name, fn in (("jacobi (csrc/eigh.hip)", lambda: eigh.syevj_small(a)), ("torch.linalg.eigh", lambda: torch.linalg.eigh(a))):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            print(f"\n[8,{c},{c}] {name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms", end="")
+        print(f"   sweeps {eigh._small_pending[-1].tolist()}")
+    eigh.check()
