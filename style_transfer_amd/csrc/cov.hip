@@ -22,12 +22,22 @@ constexpr int LSF = KN + 1;   // odd LDS row stride (forward)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Tile pair (ti <= tj) of the upper triangle for a linear index: cov is symmetric, the strictly lower tiles are
+// never computed (C = 512: 10 of 16 tiles) -- cov_reduce_kernel mirrors them.
+__device__ __forceinline__ void tri_tile(int idx, int tiles, int& ti, int& tj) {
+  int row = 0, left = idx;
+  while (left >= tiles - row) { left -= tiles - row; ++row; }
+  ti = row;
+  tj = row + left;
+}
+
 template <int T>
 __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x,
                                                     const float* __restrict__ mean,
                                                     float* __restrict__ slabs, int B, int C, int n,
                                                     int chunks_per_split) {
   constexpr int MT = T / 64;
+  constexpr int R = T / 4;      // rows each wave stages per operand
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xi = smem;
   float* Xj = smem + T * LSF;
@@ -35,12 +45,16 @@ __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles = (C + T - 1) / T;
-  const int i0 = (blockIdx.x / tiles) * T, j0 = (blockIdx.x % tiles) * T;
+  int ti, tj;
+  tri_tile(blockIdx.x, tiles, ti, tj);
+  const bool diag = ti == tj;                  // both operands are the same rows: stage them once
+  const int i0 = ti * T, j0 = tj * T;
   const int split = blockIdx.y, b = blockIdx.z;
   const float* xb = x + (size_t)b * C * n;
   const float* mb = mean + (size_t)b * C;
   const int nchunks = (n + KN - 1) / KN;
   const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, nchunks);
+  const float* Xjr = diag ? Xi : Xj;
 
   f32x16 acc[MT][MT];
 #pragma unroll
@@ -50,34 +64,45 @@ __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[a][c][k] = 0.f;
 
-  // staging: wave w loads rows w, w+4, ...; lane = pixel of the chunk (coalesced 256-B rows)
+  // per-row constants of this wave's staging rows (wave w stages rows w, w+4, ...; lane = pixel of the chunk)
+  float mi[R], mj[R];
+  const float* ri[R];
+  const float* rj[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = wave + 4 * r;
+    const int gi = min(i0 + row, C - 1), gj = min(j0 + row, C - 1);
+    mi[r] = mb[gi]; mj[r] = mb[gj];
+    ri[r] = xb + (size_t)gi * n; rj[r] = xb + (size_t)gj * n;
+  }
+  float vi[R], vj[R];
+  auto load = [&](int ch) {                       // coalesced 256-B row segments, clamped (masked at the LDS store)
+    const int pc = min(ch * KN + lane, n - 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      vi[r] = ri[r][pc];
+      if (!diag) vj[r] = rj[r][pc];
+    }
+  };
+  if (c_begin < c_end) load(c_begin);
   for (int ch = c_begin; ch < c_end; ++ch) {
-    const int p = ch * KN + lane;
-    const bool pok = p < n;
-    const int pc = min(p, n - 1);
-    float vi[T / 4], vj[T / 4];
+    const bool pok = ch * KN + lane < n;
+    __syncthreads();                               // the previous chunk's MFMA reads are done
 #pragma unroll
-    for (int r = 0; r < T / 4; ++r) {
+    for (int r = 0; r < R; ++r) {
       const int row = wave + 4 * r;
-      const int gi = min(i0 + row, C - 1), gj = min(j0 + row, C - 1);
-      vi[r] = xb[(size_t)gi * n + pc] - mb[gi];
-      vj[r] = xb[(size_t)gj * n + pc] - mb[gj];
+      Xi[row * LSF + lane] = (pok && i0 + row < C) ? vi[r] - mi[r] : 0.f;      // exactly the reference's x - mu
+      if (!diag) Xj[row * LSF + lane] = (pok && j0 + row < C) ? vj[r] - mj[r] : 0.f;
     }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < T / 4; ++r) {
-      const int row = wave + 4 * r;
-      Xi[row * LSF + lane] = (pok && i0 + row < C) ? vi[r] : 0.f;
-      Xj[row * LSF + lane] = (pok && j0 + row < C) ? vj[r] : 0.f;
-    }
-    __syncthreads();
+    if (ch + 1 < c_end) load(ch + 1);              // next chunk's global loads fly under this chunk's MFMAs
 #pragma unroll 8
     for (int s = 0; s < KN / 2; ++s) {
       float a[MT], bb[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         a[m] = Xi[(wm * MT * 32 + m * 32 + li) * LSF + 2 * s + lh];
-        bb[m] = Xj[(wn * MT * 32 + m * 32 + li) * LSF + 2 * s + lh];
+        bb[m] = Xjr[(wn * MT * 32 + m * 32 + li) * LSF + 2 * s + lh];
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -100,12 +125,20 @@ __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// Fixed-order sum of the split-K slabs; element (i, j) of a strictly-lower TILE is read from (j, i) of the upper
+// tile that was computed (within a diagonal tile both triangles exist and are bit-identical: the same products in
+// the same order with the factors swapped).  cov comes out exactly symmetric.
 __global__ __launch_bounds__(256) void cov_reduce_kernel(const float* __restrict__ slabs,
-                                                        float* __restrict__ out, long long n, int nsplit) {
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
+                                                        float* __restrict__ out, int B, int C, int T, int nsplit) {
+  const long long cc = (long long)C * C, total = cc * B;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
+    const long long bb = e / cc;
+    const int r = int(e - bb * cc);
+    const int i = r / C, j = r - i * C;
+    const long long src = (i / T <= j / T) ? (long long)i * C + j : (long long)j * C + i;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[(size_t)k * n + e];
+    for (int k = 0; k < nsplit; ++k) s += slabs[((size_t)k * B + bb) * cc + src];
     out[e] = s;
   }
 }
@@ -215,7 +248,7 @@ Plan plan_for(int B, int C, int n) {
   p.T = C <= 64 ? 64 : 128;
   p.tiles = st::cdiv(C, p.T);
   const int nchunks = st::cdiv(n, KN);
-  const int base = B * p.tiles * p.tiles;
+  const int base = B * (p.tiles * (p.tiles + 1) / 2);      // upper-triangular tile pairs only
   int want = std::max(1, 1024 / std::max(1, base));
   p.nsplit = std::max(1, std::min(want, nchunks));
   p.chunks_per_split = st::cdiv(nchunks, p.nsplit);
@@ -237,7 +270,7 @@ extern "C" int st_cov_fwd(const float* x, const float* mean, float* cov, float* 
   ST_REQUIRE(b > 0 && c > 0 && n > 0, "st_cov_fwd: bad dims b=%d c=%d n=%d", b, c, n);
   const Plan p = plan_for(b, c, n);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(p.tiles * p.tiles, p.nsplit, b);
+  dim3 grid(p.tiles * (p.tiles + 1) / 2, p.nsplit, b);
   if (p.T == 64) {
     hipLaunchKernelGGL(cov_fwd_kernel<64>, grid, dim3(NT), 2 * 64 * LSF * sizeof(float), s, x, mean,
                        workspace, b, c, n, p.chunks_per_split);
@@ -248,7 +281,7 @@ extern "C" int st_cov_fwd(const float* x, const float* mean, float* cov, float* 
   }
   const long long total = (long long)b * c * c;
   hipLaunchKernelGGL(cov_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(total, 256), 2048)),
-                     dim3(256), 0, s, workspace, cov, total, p.nsplit);
+                     dim3(256), 0, s, workspace, cov, b, c, p.T, p.nsplit);
   return st::check_launch("st_cov_fwd");
 }
 

@@ -69,6 +69,14 @@ def main():
             line(f"mse fwd  [{b},{c},{hw},{hw}]", timeit(lambda: mse(f, f2)), nbytes=8.0 * f.numel())
             line(f"covariance (Gram) fwd  [{b},{c},{hw},{hw}]", timeit(lambda: vin.calc_2_moments(f)),
                  flops=2.0 * b * c * c * hw * hw)
+        fc = f.clone().requires_grad_(True)
+        gc = torch.randn(b, c, c, device=dev, generator=g)
+
+        def cb():
+            fc.grad = None
+            mu, cov = vin.calc_2_moments(fc)
+            (cov * gc).sum().backward()
+        line(f"covariance (Gram) fwd+bwd  [{b},{c},{hw},{hw}]", timeit(cb), flops=6.0 * b * c * c * hw * hw)
         fg = f.clone().requires_grad_(True)
 
         def sb():
