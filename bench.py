@@ -54,12 +54,36 @@ DOMINANT = "conv3x3_f32_kernel<2,2,2,2>"
 DOMINANT_BF16 = "conv3x3_bf16_kernel<2,4,2,4>"
 DOMINANT_BF16X3 = "conv3x3_bf16x3_kernel<1,4,2,4>"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
-# HBM bytes per launch of the dominant kernel from profiles/r1_bench_infer_pmc_hbm.csv (FETCH_SIZE + WRITE_SIZE
-# KiB, averaged over the launches of its 3-blocks-per-CU instantiation (19 of the 20 launches per inference step);
-# 4-B-per-lane loads: FETCH_SIZE taken as reported)
-DOMINANT_TRAFFIC_BYTES = (568828.8 + 248346.9) * 1024
-# same file: the G8 -> G8 instantiation of the bf16 kernel (1003 launches: FETCH_SIZE + WRITE_SIZE, KiB per launch)
-DOMINANT_BF16_TRAFFIC_BYTES = (111085.6 + 131072.0) * 1024
+
+
+def pmc_traffic(kernel: str, fetch_factor: float = 1.0):
+    """HBM bytes per launch of `kernel` (FETCH_SIZE * fetch_factor + WRITE_SIZE) read at RUN TIME from the newest
+    profiles/r*_bench_infer_pmc_hbm.csv (separate rocprofv3 --pmc passes of this command, tools/collect_profiles.sh;
+    KiB per dispatch; fetch_factor 2 = the gfx950 correction for 16-B-per-lane streaming reads).  The most-launched
+    instantiation whose name starts with `kernel` is taken.  Returns (bytes, file name); raises SystemExit if the file
+    or the kernel is missing -- a renamed kernel must not silently keep a stale number."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_infer_pmc_hbm.csv")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        raise SystemExit("bench.py: no profiles/r*_bench_infer_pmc_hbm.csv to take roofline.traffic from")
+    want = kernel.replace(" ", "").rstrip(">")
+    best = {}
+    for r in csv.DictReader(open(files[-1])):
+        name = r["Name"].replace(" ", "")
+        if name.startswith(want):
+            key = (name, r["Counter"])
+            best[key] = (int(r["Calls"]), float(r["AvgValueKiBPerDispatch"]))
+    names = {n for n, _ in best}
+    if not names:
+        raise SystemExit(f"bench.py: kernel {kernel!r} not found in {files[-1]} (re-run tools/collect_profiles.sh)")
+    top = max(names, key=lambda n: best.get((n, "FETCH_SIZE"), (0, 0))[0])
+    if (top, "FETCH_SIZE") not in best or (top, "WRITE_SIZE") not in best:
+        raise SystemExit(f"bench.py: {files[-1]} lacks FETCH_SIZE / WRITE_SIZE rows for {top}")
+    kib = best[(top, "FETCH_SIZE")][1] * fetch_factor + best[(top, "WRITE_SIZE")][1]
+    return kib * 1024.0, os.path.basename(files[-1])
 
 
 def encoder_decoder_flops(side: int):
@@ -99,11 +123,40 @@ def train_flops_per_image(side: int) -> float:
     return (2 * enc + dec + 2 * l21 + 2 * l25) + 2 * dec + (l21 + l25)
 
 
-def cpu_baseline_infer(pairs: int = 8, runs: int = 3):
-    """Time the CPU oracle on a bounded sample: `pairs` 512x512 content/style pairs, alpha=1."""
+def host_cpu():
+    """(model name, physical cores of the machine, CPUs this process may run on) from /proc/cpuinfo."""
+    model, phys = "unknown", set()
+    try:
+        pid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                phys.add((pid, ln.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    return model, len(phys) or None, allowed
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def cpu_baseline_infer(pairs: int = 4, runs: int = 5):
+    """Time the CPU oracle on a bounded sample: `pairs` 512x512 content/style pairs, alpha=1; median of `runs`
+    (median of >= 5 after a warm-up)."""
     from oracle import ref_ops as R
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
+    model, phys, allowed = host_cpu()
     enc_sd, dec_sd = R.make_encoder_state(0), R.make_decoder_state(1)
     g = torch.Generator().manual_seed(1234)
     c = torch.rand(pairs, 3, SIDE, SIDE, generator=g)
@@ -115,13 +168,15 @@ def cpu_baseline_infer(pairs: int = 8, runs: int = 3):
             t0 = time.perf_counter()
             R.stylize(c, s, enc_sd, dec_sd)
             times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": round(pairs / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{pairs} content/style pairs at {SIDE}x{SIDE} fp32, alpha=1, best of {runs} runs "
-                      f"of oracle.ref_ops.stylize (plain torch CPU, {cores} threads)"}
+    med = median(times)
+    return {"value": round(pairs / med, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "physical_cores_of_host": phys, "cpus_allowed": allowed,
+            "best": round(pairs / min(times), 4),
+            "sample": f"{pairs} content/style pairs at {SIDE}x{SIDE} fp32, alpha=1, median of {runs} runs after one "
+                      f"warm-up of oracle.ref_ops.stylize (plain torch CPU, {cores} threads)"}
 
 
-def cpu_baseline_train(batch: int = 2, runs: int = 2):
+def cpu_baseline_train(batch: int = 2, runs: int = 5):
     """One full training step (forward, losses, backward, Adam) of the CPU oracle at batch 2, 256x256."""
     from oracle import ref_ops as R
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
@@ -146,10 +201,13 @@ def cpu_baseline_train(batch: int = 2, runs: int = 2):
         opt.step()
         if i:
             times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": round(batch / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
+    med = median(times)
+    model, phys, allowed = host_cpu()
+    return {"value": round(batch / med, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "physical_cores_of_host": phys, "cpus_allowed": allowed,
+            "best": round(batch / min(times), 4),
             "sample": f"one training step at batch {batch}, {TRAIN_SIDE}x{TRAIN_SIDE} fp32 (mean/std style loss), "
-                      f"best of {runs} after 1 warm-up, oracle.ref_ops.train_step_losses + autograd + Adam "
+                      f"median of {runs} after 1 warm-up, oracle.ref_ops.train_step_losses + autograd + Adam "
                       f"(plain torch CPU, {cores} threads)"}
 
 
@@ -248,6 +306,91 @@ def adain_back_to_back(ctx: Ctx, args, reps: int = 20) -> float:
     return e0.elapsed_time(e1) * 1e3 / (2 * reps)
 
 
+def _b2b_us(fn, reps: int) -> float:
+    """Average duration (us) of `fn` over `reps` back-to-back calls between ONE HIP event pair on the launch stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def roofline_aux(ctx: Ctx):
+    """Roofline objects for the loss kernels north_star names next to the convs: RGB-uv histogram and TV (HBM GB/s)
+    and the covariance "Gram" kernel (fp32 MFMA TFLOP/s).  Each is timed back to back through the module API at the
+    BASELINE configs[2] shape (B = 8, 256x256: a few MB -- launch-latency-bound, reported as such) and at a shape that
+    says something about the kernel (B = 16 at 2048x2048 for the image kernels, 806 MB: nothing stays in the 256 MB
+    Infinity Cache; [16, 512, 64, 64] for the covariance).  Algorithmic bytes / FLOPs as in SURVEY 8d."""
+    import warnings
+    from style_transfer_amd import ops
+    from style_transfer_amd.losses import HistLoss, TVLoss, VincentStyleLoss
+    dev = ctx.dev
+    g = torch.Generator(device=dev).manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hist, tv, vin = HistLoss().histogram_block, TVLoss(), VincentStyleLoss()
+    out = {}
+    with torch.no_grad():
+        rows_h, rows_t = {}, {}
+        for tag, b, side, reps in (("configs2", 8, 256, 50), ("large", 16, 2048, 10)):
+            x = torch.rand(b, 3, side, side, device=dev, generator=g)
+            hb = 4.0 * (x.numel() + b * 3 * 64 * 64)
+            us = _b2b_us(lambda: hist(x), reps)
+            rows_h[tag] = {"shape": [b, 3, side, side], "avg_call_us": round(us, 1), "mbytes": round(hb / 1e6, 2),
+                           "gbs": round(hb / us / 1e3, 1)}
+            tb = 4.0 * x.numel()
+            us = _b2b_us(lambda: tv(x), reps)
+            rows_t[tag] = {"shape": [b, 3, side, side], "avg_call_us": round(us, 1), "mbytes": round(tb / 1e6, 2),
+                           "gbs": round(tb / us / 1e3, 1)}
+            del x
+        for name, rows, kern in (("roofline_hist", rows_h, "hist_prep_kernel + hist_accum_kernel + hist_sum_slabs_kernel + "
+                                  "hist_normalize_kernel (one RGBuvHistBlock.forward)"),
+                                 ("roofline_tv", rows_t, "tv_rows_partial_kernel + finalize_kernel (one TVLoss.forward)")):
+            big = rows["large"]
+            out[name] = {"bound": "hbm", "achieved": big["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(big["gbs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kern,
+                         "shape": big["shape"], "avg_call_us": big["avg_call_us"], "avg_call_mbytes": big["mbytes"],
+                         "at_configs2_shape": dict(rows["configs2"], note="a few MB per call: launch-latency-bound"),
+                         "method": "calls back to back between one HIP event pair on the launch stream"}
+        # covariance: the five style layers of a configs[2] step (B = 8, 256x256 input), then one large problem
+        feats = [torch.randn(8, c, hw, hw, device=dev, generator=g) for c, hw in ((64, 256), (128, 128), (256, 64), (512, 32), (512, 32))]
+        means = [ops.mean_std(f)[0].reshape(f.shape[0], f.shape[1]) for f in feats]
+
+        def cov_only(f, m):
+            from style_transfer_amd import _lib
+            lib = _lib.load()
+            b, c, h, w = (int(v) for v in f.shape)
+            cov = torch.empty((b, c, c), device=dev)
+            ws = torch.empty(lib.st_cov_workspace_bytes(b, c, h * w) // 4, device=dev)
+
+            def call():
+                _lib.check(lib.st_cov_fwd(_lib.dev_ptr(f), _lib.dev_ptr(m), _lib.dev_ptr(cov), _lib.dev_ptr(ws), b, c, h * w,
+                                          _lib.stream_ptr()), "st_cov_fwd")
+            return call
+        calls = [cov_only(f, m) for f, m in zip(feats, means)]
+        us5 = _b2b_us(lambda: [c() for c in calls], 20)
+        fl5 = sum(2.0 * f.shape[0] * f.shape[1] ** 2 * f.shape[2] * f.shape[3] for f in feats)
+        fbig = torch.randn(16, 512, 64, 64, device=dev, generator=g)
+        mbig = ops.mean_std(fbig)[0].reshape(16, 512)
+        usb = _b2b_us(cov_only(fbig, mbig), 10)
+        flb = 2.0 * 16 * 512 * 512 * 64 * 64
+        tfb = flb / usb / 1e6
+        out["roofline_cov"] = {"bound": "mfma", "achieved": round(tfb, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tfb / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "kernel": "cov_fwd_kernel<128> + cov_reduce_kernel (st_cov_fwd)", "shape": [16, 512, 64, 64],
+                               "avg_call_us": round(usb, 1), "avg_call_gflop": round(flb / 1e9, 2),
+                               "at_configs2_shapes": {"layers": "[8,64,256,256] [8,128,128,128] [8,256,64,64] 2x[8,512,32,32]",
+                                                      "five_calls_us": round(us5, 1), "gflop": round(fl5 / 1e9, 2),
+                                                      "tflops": round(fl5 / us5 / 1e6, 2),
+                                                      "note": "4.3 GFLOP per call: ~1 round of blocks, launch-latency-bound"},
+                               "method": "calls back to back between one HIP event pair on the launch stream"}
+    return out
+
+
 def run_inference(ctx: Ctx, args, compute: str = "f32"):
     from oracle import ref_ops as R     # seeded synthetic weights only
     from style_transfer_amd.generator import Decoder, Encoder
@@ -295,7 +438,7 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
                 "model_tflops": round(value * per_img / 1e12, 2),
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                             "traffic": round(DOMINANT_BF16_TRAFFIC_BYTES)
+                             "traffic": round(pmc_traffic("conv3x3_bf16_kernel<2,4,2,4,false,false,false,false,true,true")[0])
                              if (not x3 and args.batch == BATCH and args.side == SIDE) else None,
                              "kernel": dom_name,
                              "mfma_flops_per_algorithmic_flop": mul,
@@ -308,19 +451,22 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
     secs = sum(r["ms"] for r in dom) * 1e-3
     achieved = flops / secs / 1e12 if secs > 0 else 0.0
     default_shape = args.batch == BATCH and args.side == SIDE
+    traffic, traffic_file = pmc_traffic(DOMINANT) if default_shape else (None, None)
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": round(DOMINANT_TRAFFIC_BYTES) if default_shape else None,
-            "traffic_note": "HBM bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r1_bench_infer_pmc_hbm.csv "
-                            "(separate --pmc passes of this command)",
+            "traffic": round(traffic) if traffic else None,
+            "traffic_note": f"HBM bytes per launch, FETCH_SIZE + WRITE_SIZE read at run time from profiles/{traffic_file} "
+                            "(separate rocprofv3 --pmc passes of this command; most-launched instantiation)",
             "kernel": DOMINANT, "launches": len(dom),
             "avg_launch_us": round(secs / max(1, len(dom)) * 1e6, 2),
             "avg_launch_gflop": round(flops / max(1, len(dom)) / 1e9, 3),
             "all_conv_tflops": round(sum(r["flops"] for r in allconv) /
                                      max(1e-12, sum(r["ms"] for r in allconv) * 1e-3) / 1e12, 2),
             "all_conv_time_frac_of_step": round(sum(r["ms"] for r in allconv) * 1e-3 / elapsed, 4),
-            "method": "HIP event pair around every launch on the launch stream, over a repeat of the K timed "
-                      "steps run right after them (events inside the timed region open launch gaps on some boxes)",
+            "method": "HIP event pair around every launch on the launch stream, over a REPEAT of the K timed "
+                      "steps run right after them -- not the timed loop itself (events inside the timed region open "
+                      "launch gaps on some boxes), so all_conv_time_frac_of_step relates two different loops and "
+                      "may exceed 1",
             "ms_per_step_instrumented": round(elapsed_ev / args.steps * 1e3, 3)}
     ad = [r for r in records if r["kernel"].startswith("adain")]
     ad_bytes = sum(r["bytes"] for r in ad)
@@ -343,8 +489,8 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
                   "in_step_achieved": round(ad_gbs_step, 1),
                   "avg_launch_mbytes": round(ad_bytes / max(1, len(ad)) / 1e6, 2),
                   "traffic": round(ad_bytes / max(1, len(ad))) if default_shape else None,
-                  "traffic_note": "PMC: 2 x FETCH_SIZE (gfx950 16-B/lane correction) + WRITE_SIZE = 402.7 MB = "
-                                  "algorithmic bytes (profiles/r1_bench_infer_pmc_hbm.csv)"}
+                  "traffic_note": "algorithmic bytes; the PMC passes agree: 2 x FETCH_SIZE (gfx950 16-B/lane "
+                                  "correction) + WRITE_SIZE of adain_reg_kernel in profiles/*_bench_infer_pmc_hbm.csv"}
     return {
         "metric": "stylized 512x512 img/s (inference)", "value": round(value, 3), "unit": "img/s",
         "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
@@ -458,6 +604,7 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--no-gram", action="store_true", help="skip the VincentStyleLoss variant of the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the roofline_hist / roofline_tv / roofline_cov objects")
     ap.add_argument("--no-hip-graph", action="store_true", help="skip the HIP-graph-replay variants of the train legs")
     ap.add_argument("--compute", choices=["f32", "bf16", "bf16x3"], default="f32",
                     help="conv compute precision of the main legs (profiling aid; the headline legs are f32)")
@@ -514,6 +661,8 @@ def main():
             tgt["hip_graph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "launch")}
         except Exception as e:      # noqa: BLE001
             tgt["hip_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if ctx.world == 1 and args.mode == "both" and not args.no_aux:
+        line.update(roofline_aux(ctx))
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline:
             if args.mode in ("both", "infer"):

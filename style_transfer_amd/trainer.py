@@ -668,7 +668,28 @@ class Trainer:
         run_step = GraphedStep(self, step_engine, transformer_optimizer, bucket) if self.graph_capable() else \
             (lambda c, s: self.optimize_step(step_engine, transformer_optimizer, bucket, c, s))
         history = []
-        for epoch in range(init_epoch, self.num_train_epochs):
+        if self.rank == 0:       # what the reference announces before its loop (trainer.py:396-413), one line per fact
+            n_examples = len(train_loader.dataset) if hasattr(train_loader, "dataset") else "?"
+            facts = [("epochs", self.num_train_epochs), ("first epoch of this run", init_epoch),
+                     ("style loss", "VincentStyleLoss" if self.use_VincentStyleLoss else "AdaINStyleLoss"),
+                     ("optimizer", self.optim_name), ("gradient threshold", self.gradient_threshold),
+                     ("grayscale content", self.grayscale_content_transform), ("eps limit", self.eps),
+                     ("decoder trained", self.do_decoder_train), ("WCT decoder weights", self.use_pretrained_WCTDECODER),
+                     ("batch per process", self.per_device_batch_size), ("processes", self.world_size),
+                     ("batches per epoch", steps_per_epoch), ("examples", n_examples),
+                     ("optimizer steps in total", steps_per_epoch * (self.num_train_epochs - init_epoch)),
+                     ("batches between LR steps", scheduler_steps), ("content layers", self.content_layers_idx),
+                     ("style layers", self.style_layers_idx), ("device", self.device),
+                     ("conv compute", self.compute_dtype), ("HIP-graph replay", self.graph_capable())]
+            print("\n --- training set-up ---\n" + "\n".join(f"   {k}: {v}" for k, v in facts) + "\n")
+        epochs = range(init_epoch, self.num_train_epochs)
+        if self.rank == 0:
+            try:        # the reference's epoch progress bar (trainer.py:416-417)
+                from tqdm import tqdm
+                epochs = tqdm(epochs, desc="Training progress", colour='green', position=0, leave=True)
+            except ImportError:
+                pass
+        for epoch in epochs:
             sums = torch.zeros(5, dtype=torch.float64, device=self.device)
             step_log = torch.zeros((steps_per_epoch, 5), dtype=torch.float32, device=self.device) if self.log_steps else None
             transformer.train()
@@ -701,10 +722,15 @@ class Trainer:
                     for i, (c_, s_, v_, h_, t_) in enumerate(history[-1]["steps"]):
                         print(f"     step {i}: content {c_:.6g} style {s_:.6g} variation {v_:.6g} hist {h_:.6g} "
                               f"total {t_:.6g}")
-            if self.rank == 0:
+            if self.rank == 0:       # the per-epoch report of trainer.py:514-525: raw and weighted terms, eps, best so far
                 epss = transformer.get_current_eps()
-                print(f"   Epoch [{epoch + 1}/{self.num_train_epochs}] total {avg_total} content {avg_content} "
-                      f"style {avg_style} variation {avg_var} hist {avg_hist} eps(style, content) {epss}")
+                rows = [("content", avg_content, self.alpha), ("style", avg_style, self.beta),
+                        ("variation", avg_var, self.gamma), ("histogram", avg_hist, self.delta)]
+                print(f"\n --- epoch {epoch + 1} of {self.num_train_epochs} ---\n"
+                      f"   total loss {avg_total}   (best of this session: {min(loss_list)})\n" +
+                      "".join(f"   {name:9s} {val}   weighted {val * wgt}\n" for name, val, wgt in rows) +
+                      f"   eps in use: style {epss[0]} (parameter {float(transformer.style_eps.detach())}), "
+                      f"content {epss[1]} (parameter {float(transformer.content_eps.detach())})")
             info = {"total": avg_total, "content": avg_content, "style": avg_style, "epoch": epoch,
                     "completed_step": completed_step}
             plots = None

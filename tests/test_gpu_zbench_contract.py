@@ -34,6 +34,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["train"]["value"] > 0 and d["bf16"]["inference"]["value"] > 0 and d["bf16x3"]["inference"]["value"] > 0
+    for name, bound, unit in (("roofline_hist", "hbm", "GB/s"), ("roofline_tv", "hbm", "GB/s"), ("roofline_cov", "mfma", "TFLOP/s")):
+        o = d[name]
+        assert o["bound"] == bound and o["unit"] == unit and 0 < o["frac"] < 1 and "traffic" in o, name
+        assert abs(o["frac"] - o["achieved"] / o["peak"]) < 1e-3
 
 
 def test_bench_gpus_2_starts_its_own_ranks():

@@ -37,6 +37,21 @@ echo "[6/6] PMC pass: WRITE_SIZE"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $S/write -o p -- \
     python3 "$R/bench.py" --mode infer --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> "$O/pmc_write.err"
 python3 "$R/tools/pmc_hbm_csv.py" $S/fetch $S/write > "$O/bench_infer_pmc_hbm.csv"
+
+echo "[7] loss kernels (histogram, TV, covariance, mean/std, MSE): kernel stats + FETCH_SIZE / WRITE_SIZE passes"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/aux -o p -- \
+    python3 "$R/tools/bench_aux_kernels.py" > "$O/aux_kernels.txt" 2> "$O/aux.err"
+cp "$(find $S/aux -name '*kernel_stats.csv' | head -1)" "$O/aux_kernel_stats.csv"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $S/auxf -o p -- \
+    python3 "$R/tools/bench_aux_kernels.py" > /dev/null 2> "$O/aux_fetch.err"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $S/auxw -o p -- \
+    python3 "$R/tools/bench_aux_kernels.py" > /dev/null 2> "$O/aux_write.err"
+python3 "$R/tools/pmc_hbm_csv.py" $S/auxf $S/auxw > "$O/aux_pmc_hbm.csv"
+
+echo "[8] kernel stats, Gram-variant training step"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/gram -o p -- \
+    python3 "$R/tools/gram_step.py" 12 > /dev/null 2> "$O/gram.err"
+cp "$(find $S/gram -name '*kernel_stats.csv' | head -1)" "$O/train_gram_kernel_stats.csv"
 rm -rf $S
 rm -f "$O"/*.err
 echo done
