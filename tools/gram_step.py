@@ -1,6 +1,7 @@
 """A few Gram-variant (VincentStyleLoss) training steps at BASELINE configs[2] -- profiling target."""
 import sys, warnings, contextlib, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ref_ops as R
 from style_transfer_amd.trainer import GradBucket, Trainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
