@@ -227,7 +227,9 @@ class Ctx:
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
         self.dist = None
-        if self.world > 1:
+        # ST_FORCE_DP=1 under a launcher: initialise the group (RCCL) even for ONE rank, so that a 1-GPU box can
+        # drive the data-parallel legs through the real backend (Trainer.dp_active)
+        if self.world > 1 or ("WORLD_SIZE" in os.environ and os.environ.get("ST_FORCE_DP")):
             from style_transfer_amd.parallel import init_process_group
             self.dist, self.dev = init_process_group(rehearsal=rehearsal, local_rank=self.local_rank)
 
@@ -558,15 +560,15 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
             "dtype": compute, "style_loss": "VincentStyleLoss (covariance MFMA + eigh)" if use_vincent
             else "AdaINStyleLoss (mean/std)",
             "launch": ("eager launches" if graphed is None else "one HIP graph replay per step (GraphedStep)"
-                       if ctx.world == 1 else "three HIP graph replays per step around the two eager all-reduces "
-                                              "(GraphedStep, data parallel)"),
+                       if not tr.dp_active else "three HIP graph replays per step around the two eager all-reduces "
+                                                "(GraphedStep, data parallel)"),
             "config": {"workload": ("BASELINE configs[2]: " if (compute, tb, s) == ("f32", 8, 256) else "") +
                                    f"training step batch {tb} at {s}x{s} {compute} per "
                                    "GPU: 2x encoder, AdaIN, decoder, Normalize, loss VGG19 (idx 21 / 2,7,14,19,25), "
                                    "content + style + TV + RGB-uv histogram losses, backward, Adam(decoder + eps)",
                        "batch_per_gpu": tb, "side": s,
-                       "parallelism": f"dp{ctx.world}: batch sharded, one 14.02 MB fp32 RCCL all-reduce + 2 scalar "
-                                      "all-reduces per step" if ctx.world > 1 else "single GPU",
+                       "parallelism": f"dp{ctx.world}: batch sharded, one 14.02 MB fp32 RCCL all-reduce + one 2-float "
+                                      "all-reduce per step" if tr.dp_active else "single GPU",
                        "gflop_per_image_necessary": round(per_img / 1e9, 2)},
             "model_tflops": round(value * per_img / 1e12, 2), "final_total_loss": round(total, 4)}
 

@@ -112,7 +112,7 @@ class GradBucket:
 
     def all_reduce_sum(self) -> None:
         dist = _dist()
-        if dist is not None and dist.get_world_size() > 1:
+        if dist is not None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
     def reduce_mean(self) -> None:
@@ -277,7 +277,7 @@ class GraphedStep:
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # side-stream warm-up: intended
         self.bucket.attach()
-        if tr.world_size == 1:
+        if not tr.dp_active:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self.losses = self._eager(self.static_content, self.static_style)
@@ -405,6 +405,9 @@ class Trainer:
         dist = _dist()
         self.rank = dist.get_rank() if dist is not None else 0
         self.world_size = dist.get_world_size() if dist is not None else 1
+        # ST_FORCE_DP=1 with an initialised process group: take the data-parallel code path (both all-reduces, the
+        # three-graph replay) even with ONE rank -- lets a 1-GPU box drive the real RCCL backend through it
+        self.dp_active = self.world_size > 1 or (dist is not None and bool(os.environ.get("ST_FORCE_DP")))
 
     # ---- factories ------------------------------------------------------------------------
     @staticmethod
@@ -615,31 +618,40 @@ class Trainer:
 
     def step_backward(self, step: StyleTransferStep, partials, q_sum, global_batch: int):
         """Rest of compute_loss from the batch-wide q, then backward into the bucket (trainer.py:472)."""
-        q = _InjectReducedQ.apply(partials[3], q_sum, self.world_size) if self.world_size > 1 else partials[3]
+        q = _InjectReducedQ.apply(partials[3], q_sum, self.world_size) if self.dp_active else partials[3]
         losses = step.combine(partials, q, global_batch)
         losses[4].backward()
         return losses
 
     def step_update(self, step: StyleTransferStep, optimizer, bucket: GradBucket):
         """[1 / world_size] / [AdaIN grad clamp, AFTER the reduction] / optimizer.step (trainer.py:392-394, 473)."""
-        if self.world_size > 1:
+        if self.dp_active:
             bucket.flat.div_(self.world_size)
         if self.gradient_threshold is not None:
             for p in step.transformer.parameters():
                 if p.grad is not None:
                     p.grad.clamp_(-self.gradient_threshold, self.gradient_threshold)
+        # an eps parameter in a clamped branch of adjust_sigmoid gets no gradient in the reference (transformer.py:
+        # 32-35 returns a Python float) and is therefore never moved by the optimizer; keep it bit-identical here too
+        # (weight decay or left-over momentum would otherwise move it on a zero gradient) -- device-side, no host read
+        eps_params = (step.transformer.content_eps, step.transformer.style_eps)
+        masks = step.transformer.clamped_masks()
+        before = [p.detach().clone() for p in eps_params]
         optimizer.step()
+        with torch.no_grad():
+            for p, old, m in zip(eps_params, before, masks):
+                p.copy_(torch.where(m, old, p))
 
     def optimize_step(self, step: StyleTransferStep, optimizer, bucket: GradBucket, content_imgs, style_imgs):
         """zero_grad / backward / [grad all-reduce] / [AdaIN grad clamp] / optimizer.step (trainer.py:471-473, 392-394)."""
         partials = self.step_forward(step, bucket, content_imgs, style_imgs)
         q_sum = partials[3]
-        if self.world_size > 1:
+        if self.dp_active:
             dist = _dist()
             q_sum = partials[3].detach().clone()
             dist.all_reduce(q_sum, op=dist.ReduceOp.SUM)
         losses = self.step_backward(step, partials, q_sum, content_imgs.shape[0] * self.world_size)
-        if self.world_size > 1:
+        if self.dp_active:
             bucket.all_reduce_sum()
         self.step_update(step, optimizer, bucket)
         return losses

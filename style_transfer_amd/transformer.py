@@ -44,6 +44,18 @@ class AdaIN(nn.Module):
         float (clamped, no gradient) the clamp passes a ZERO gradient to the parameter instead of none."""
         return torch.pow(torch.abs(x), 0.5).clamp(1e-5, upper_limit)
 
+    def clamped_masks(self):
+        """Per eps parameter, a 1-element device bool: True where adjust_sigmoid takes one of its two constant
+        branches.  There the reference hands the optimizer NO gradient (a Python float carries no graph), so the
+        parameter is not touched at all -- no update, no weight decay, no momentum drift; the trainer uses these
+        masks to restore a clamped parameter after ``optimizer.step()`` (the device-side clamp delivers a zero
+        gradient instead of none)."""
+        out = []
+        for p in (self.content_eps, self.style_eps):
+            x = torch.pow(torch.abs(p.detach()), 0.5)
+            out.append((x < 1e-5) | (x > self.eps_limit))
+        return out
+
     def get_current_eps(self):
         """transformer.py:38-44."""
         if torch.cuda.is_available():

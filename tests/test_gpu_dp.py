@@ -139,3 +139,48 @@ def test_two_rank_step_equals_large_batch_step():
             assert torch.allclose(a, b, rtol=1e-5, atol=0), (step, r, a, b)
         assert _rel_l2(gr["grads"][step], got["grads"][step]) < 1e-5, step
     assert _rel_l2(gr["weights"], got["weights"]) < 1e-5
+
+
+# ---- the real RCCL backend, one rank ---------------------------------------------------------------------------
+def _rccl_worker(port, q):
+    """ONE rank on backend "nccl" (= RCCL) with ST_FORCE_DP=1: the data-parallel code path -- both all-reduces per
+    step, the three-graph replay with eager collectives between the replays, graph capture next to the process
+    group's watchdog thread -- runs through the real backend on the real device."""
+    sys.path.insert(0, REPO)
+    os.environ["ST_FORCE_DP"] = "1"
+    from style_transfer_amd.parallel import init_process_group
+    dist, _ = init_process_group(rehearsal=False, local_rank=0, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl"
+    batches = _batches()
+    result = {}
+    for name, use_graph in (("eager", False), ("graph", True)):
+        tr, run, bucket, decoder, transformer = _make(use_graph=use_graph)
+        assert tr.world_size == 1 and tr.dp_active
+        grads, losses, weights = _trajectory(run, bucket, decoder, transformer, batches, 0, PER_RANK)
+        if use_graph:
+            assert len(run.graphs) == 3 and run.replays == STEPS - run.WARMUP
+        result[name] = {"grads": [g.numpy() for g in grads], "losses": [l.numpy() for l in losses], "weights": weights.numpy()}
+    q.put(result)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forced_data_parallel_path_on_real_rccl_with_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29700 + os.getpid() % 2000, q))
+    p.start()
+    try:
+        got = q.get(timeout=400)
+    finally:
+        p.join(timeout=120)
+    assert p.exitcode == 0
+    # the plain single-process step (no process group, no collectives) on the same batches
+    tr, run, bucket, decoder, transformer = _make(use_graph=False)
+    assert not tr.dp_active
+    grads, losses, weights = _trajectory(run, bucket, decoder, transformer, _batches(), 0, PER_RANK)
+    for name in ("eager", "graph"):
+        for step in range(STEPS):
+            assert torch.allclose(torch.as_tensor(got[name]["losses"][step]), losses[step], rtol=1e-5, atol=0), (name, step)
+            assert _rel_l2(got[name]["grads"][step], grads[step]) < 1e-5, (name, step)
+        assert _rel_l2(got[name]["weights"], weights) < 1e-5, name

@@ -241,3 +241,37 @@ def test_eager_forward_after_graph_replays_uses_current_weights():
             assert rel_l2(got, want) < 1e-6, i
             seen.append(got)
     assert rel_l2(seen[1], seen[0]) > 1e-3 and rel_l2(seen[2], seen[1]) > 1e-3     # the weights did move
+
+
+@pytest.mark.parametrize("eps_limit,moves", [(1e-5, False), (0.1, True)])
+def test_clamped_eps_parameters_are_not_touched_by_the_optimizer(eps_limit, moves):
+    """transformer.py:27-36: in a clamped branch adjust_sigmoid returns a Python float, the eps parameter gets NO
+    gradient and torch's optimizers skip it -- no update, no weight decay.  With the CLI default --eps 1e-5 the
+    parameter (init 1e-5, sqrt = 3.2e-3 > 1e-5) is always clamped.  Here the clamp lives on the device and delivers
+    a zero gradient, so the trainer restores clamped parameters after optimizer.step(): with AdamW and a large
+    weight decay they must stay bit-identical; with eps_limit 0.1 (unclamped) they must move."""
+    import warnings
+    from style_transfer_amd.trainer import GradBucket, Trainer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = Trainer({"train": []}, output_dir="/tmp/st_eps_test", num_train_epochs=1, per_device_batch_size=2,
+                     learning_rate=1e-2, alpha=1.0, beta=10.0, gamma=1.0, delta=10.0, eps=eps_limit, do_decoder_train=False,
+                     optim_name={"optim_name": "adamw", "weight_decay": 0.5}, content_layers_idx=[21],
+                     style_layers_idx=[2, 7, 14, 19, 25], encoder_weights=R.make_encoder_state(0),
+                     vgg_weights=R.make_loss_vgg_state(2, upto=25), device="cuda")
+        encoder, decoder, transformer, loss_vgg = tr.build_model()
+        decoder.load_state_dict(R.make_decoder_state(1))
+        params = tr.trainable_parameters(transformer, decoder)
+        opt = tr.get_optimizer("adamw", params, 1e-2, tr.graph_optim_kwargs())
+        step = tr.make_step(encoder, decoder, transformer, loss_vgg)
+    bucket = GradBucket(params)
+    g = torch.Generator().manual_seed(12)
+    before = [p.detach().clone() for p in transformer.parameters()]
+    for _ in range(3):
+        tr.optimize_step(step, opt, bucket, torch.rand(2, 3, 32, 32, generator=g).cuda(),
+                         torch.rand(2, 3, 32, 32, generator=g).cuda())
+    after = [p.detach().clone() for p in transformer.parameters()]
+    if moves:
+        assert all(not torch.equal(a, b) for a, b in zip(after, before))
+    else:
+        assert all(torch.equal(a, b) for a, b in zip(after, before))

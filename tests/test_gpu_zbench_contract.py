@@ -61,3 +61,26 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert "dp2" in d["train"]["config"]["parallelism"]
     assert d["train"]["hip_graph"].get("value", 0) > 0, d["train"]["hip_graph"]
     assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
+
+
+def test_bench_under_launcher_on_real_rccl_one_rank():
+    """The driver's launch form (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with N = 1
+    and ST_FORCE_DP=1: process group on backend "nccl" (RCCL), barrier / max-over-ranks / both training all-reduces
+    and the three-graph replay all go through the real backend on this box's one GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ST_FORCE_DP="1", ST_BENCH_PREWARM="0.05")
+    env.pop("ST_BENCH_REHEARSAL", None)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--mode", "train", "--train-batch", "2",
+         "--train-side", "64", "--train-steps", "3", "--train-warmup", "1", "--no-gram", "--no-bf16", "--no-cpu-baseline"],
+        capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "dp1" in d["config"]["parallelism"]
+    assert d["hip_graph"]["value"] > 0 and "three HIP graph" in d["hip_graph"]["launch"], d["hip_graph"]
