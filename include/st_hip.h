@@ -327,6 +327,32 @@ int st_syevj_small_max_dim(void);
 int st_syevj_small_batched(const float* a, float* w, float* v, int* sweeps, int batch, int c, int max_sweeps,
                            st_stream_t stream);
 
+/* ---- GPU-side training augmentations: the per-image tensor transforms composed after ToTensor
+ * in src/train.py:116-135, applied to a batch x: [n][3][h][w] in HBM with per-image parameters in small DEVICE
+ * arrays (drawn on the host).  y is a second buffer of the same shape unless stated; every call is one or a few
+ * single-pass launches.  Values follow style_transfer_amd/transforms.py, the torchvision-free restatement of the
+ * same transforms (torchvision 0.15.1 semantics; the two custom transforms: src/utils/custom_transform.py:9-46). */
+/* RGBToGrayscaleStacked(enable=True), custom_transform.py:32-46 (y may alias x). */
+int st_aug_gray_stack(const float* x, float* y, int n, int hw, st_stream_t stream);
+/* transforms.RandomRotation: nearest, same canvas, zero fill; angle_rad_dev[n] (0 = identity). */
+int st_aug_rotate(const float* x, float* y, const float* angle_rad_dev, int n, int c, int h, int w,
+                  st_stream_t stream);
+/* AddGaussianNoise, custom_transform.py:9-29: images with sigma_dev[i] >= 0 become
+ * floor(interp(interp(x, (min, max), (0, 1)) + noise, (min', max'), (0, 255))) / 255, the others are copied.
+ * noise: [n][elems] samples of N(mean, sigma_i) (the caller's RNG); minmax_ws: 2 n floats; y may alias x. */
+int st_aug_gaussian_noise(const float* x, const float* noise, const float* sigma_dev, float* y,
+                          float* minmax_ws, int n, int elems_per_image, st_stream_t stream);
+/* transforms.RandomAdjustSharpness: factor_dev[i] < 0 = image not selected. */
+int st_aug_sharpness(const float* x, float* y, const float* factor_dev, int n, int c, int h, int w,
+                     st_stream_t stream);
+/* One of ColorJitter's four adjustments per call, chosen per image: code_dev[i] = 0 brightness, 1 contrast,
+ * 2 saturation, 3 hue, other = copy; param_dev[i] = the factor (hue: the shift).  Four calls with the four columns of
+ * a per-image permutation reproduce ColorJitter's random order.  gray_mean_ws: n floats; y may alias x. */
+int st_aug_color_jitter_slot(const float* x, float* y, const int* code_dev, const float* param_dev,
+                             float* gray_mean_ws, int n, int hw, st_stream_t stream);
+/* transforms.RandomHorizontalFlip: flip_dev[i] != 0 = flip. */
+int st_aug_hflip(const float* x, float* y, const int* flip_dev, int n, int c, int h, int w, st_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NT) void adain_reg_kernel(const float* __restrict__
 // ONCE, accumulating d = x - K and d*d in fp64 with K = mean of the plane's first 512 elements
 // (shifted one-pass moments: with fp64 accumulators the cancellation in s2 - s1^2/n is far below
 // fp32 resolution), instead of being read twice.  Algorithmic traffic: content + style + out.
-constexpr int NTB = 512;
+constexpr int NTB_MAX_HW = 512 * 4 * 32;     // largest content plane adain_big_kernel holds in registers (1024 x 16 float4 = 512 x 32)
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -136,6 +136,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+template <int NTB, int V4>
 __global__ __launch_bounds__(NTB) void adain_big_kernel(const float* __restrict__ content,
                                                        const float* __restrict__ style,
                                                        float* __restrict__ out, int hw_c, int hw_s,
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(NTB) void adain_big_kernel(const float* __restrict_
                                                        float* __restrict__ stats,
     const float* __restrict__ eps_dev) {
   if (eps_dev) { eps_c = eps_dev[0]; eps_s = eps_dev[1]; }   // device-resident eps (no host read)
-  constexpr int V4 = 32, NW = NTB / 64;
+  constexpr int NW = NTB / 64;
   __shared__ float red[NW];
   __shared__ double redd[2 * NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -464,9 +465,16 @@ static int adain_fwd_impl(const float* content, const float* style, float* out, 
   } else if (vec_ok && need <= NT * 4 * 16) {
     hipLaunchKernelGGL(adain_reg_kernel<16>, grid, block, 0, s, content, style, out, hw_content,
                        hw_style, eps_content, eps_style, alpha, stats, eps_dev);
-  } else if (vec_ok && hw_content <= NTB * 4 * 32 && hw_style >= 2) {
-    hipLaunchKernelGGL(adain_big_kernel, grid, dim3(NTB), 0, s, content, style, out, hw_content,
-                       hw_style, eps_content, eps_style, alpha, stats, eps_dev);
+  } else if (vec_ok && hw_content <= NTB_MAX_HW && hw_style >= 2) {
+    // 512 threads x 32 float4.  The 1024 x 16 form (4 waves per SIMD at <= 128 registers, ST_ADAIN_BIG_1024=1) was
+    // measured SLOWER on the 2048 x 2048 case: 107 us against 77 us.
+    static const bool narrow = getenv("ST_ADAIN_BIG_1024") == nullptr;
+    if (narrow)
+      hipLaunchKernelGGL((adain_big_kernel<512, 32>), grid, dim3(512), 0, s, content, style, out, hw_content,
+                         hw_style, eps_content, eps_style, alpha, stats, eps_dev);
+    else
+      hipLaunchKernelGGL((adain_big_kernel<1024, 16>), grid, dim3(1024), 0, s, content, style, out, hw_content,
+                         hw_style, eps_content, eps_style, alpha, stats, eps_dev);
   } else {
     hipLaunchKernelGGL(adain_stream_kernel, grid, block, 0, s, content, style, out, hw_content,
                        hw_style, eps_content, eps_style, alpha, stats, eps_dev);

@@ -70,6 +70,9 @@ _FLAGS = [
     ('--vgg_weights', dict(type=str, default=None, help="torchvision vgg19 state dict (vgg19-dcbb9e9d.pth)")),
     ('--dtype', dict(choices=["f32", "bf16", "bf16x3"], default="f32", help="conv compute precision")),
     ('--hip_graph', dict(action='store_true', help="replay the training step from HIP graphs (also under data parallel)")),
+    ('--gpu_augment', dict(action='store_true',
+                           help="run the post-ToTensor augmentations (rotation, noise, sharpness, colour jitter, flip) "
+                                "on the GPU per batch (gpu_augment.py) instead of per image in the DataLoader workers")),
     ('--log_steps', dict(action='store_true',
                          help="keep the five per-batch loss scalars (trainer.py:475-480) and print them at the end of "
                               "each epoch; they stay on the device during the epoch, no per-step host read")),
@@ -98,8 +101,11 @@ def parse_args(args):
 
 
 def build_transforms(args):
-    """train.py:116-135.  (crop_width, crop_height) is passed as torchvision's (h, w) size, as there."""
+    """train.py:116-135.  (crop_width, crop_height) is passed as torchvision's (h, w) size, as there.
+    With ``--gpu_augment`` the workers stop after ToTensor; build_gpu_augment() supplies the rest."""
     crop = T.RandomCrop((args.crop_width, args.crop_height), pad_if_needed=True, padding=1)
+    if getattr(args, "gpu_augment", False):
+        return T.Compose([T.Resize(300), crop, T.ToTensor()]), T.Compose([T.Resize(300), crop, T.ToTensor()])
     content = T.Compose([
         T.Resize(300), crop, T.ToTensor(), T.RGBToGrayscaleStacked(enable=args.grayscale_content_transform),
         T.RandomRotation(degrees=90), T.RandomAdjustSharpness(sharpness_factor=1.5, p=0.5),
@@ -110,6 +116,15 @@ def build_transforms(args):
         T.RandomAdjustSharpness(sharpness_factor=1.5, p=0.5),
         T.ColorJitter(brightness=0.2, contrast=0.25, saturation=0.3, hue=0.1), T.RandomHorizontalFlip(p=0.5)])
     return content, style
+
+
+def build_gpu_augment(args, rank: int = 0):
+    """The tensor half of train.py:116-135 as two GpuAugment objects (content, style), or None."""
+    if not getattr(args, "gpu_augment", False):
+        return None
+    from .gpu_augment import GpuAugment
+    return (GpuAugment.for_content(grayscale=args.grayscale_content_transform, seed=2 * (args.seed + 7919 * rank)),
+            GpuAugment.for_style(seed=2 * (args.seed + 7919 * rank) + 1))
 
 
 def main(args):
@@ -144,7 +159,7 @@ def main(args):
         grayscale_content_transform=args.grayscale_content_transform, use_VincentStyleLoss=args.use_VincentStyleLoss,
         config=args, encoder_weights=args.encoder_weights, decoder_weights=args.decoder_weights,
         vgg_weights=args.vgg_weights, compute_dtype=args.dtype, use_hip_graph=args.hip_graph,
-        log_steps=args.log_steps)
+        log_steps=args.log_steps, gpu_augment=build_gpu_augment(args, rank))
     history = trainer.train()
     if world > 1:
         import torch.distributed as dist

@@ -365,8 +365,12 @@ class Trainer:
                  grayscale_content_transform: bool = False, use_VincentStyleLoss: bool = False,
                  content_layers_idx: List[int] = [12, 16, 21], style_layers_idx: List[int] = [0, 5, 10, 19, 28],
                  encoder_weights=None, decoder_weights=None, vgg_weights=None, device=None,
-                 compute_dtype: str = "f32", use_hip_graph: bool = False, log_steps: bool = False):
+                 compute_dtype: str = "f32", use_hip_graph: bool = False, log_steps: bool = False,
+                 gpu_augment=None):
         self.output_dir = output_dir
+        # (content, style) GpuAugment pair: the post-ToTensor half of the reference's transform_content /
+        # transform_style (train.py:116-135) applied per batch on the device; None = the loader's transforms did it
+        self.gpu_augment = gpu_augment
         self.dataloaders = dataloaders.__call__() if callable(dataloaders) else dataloaders
         self.per_device_batch_size = per_device_batch_size
         self.alpha, self.beta, self.gamma, self.delta, self.eps = alpha, beta, gamma, delta, eps
@@ -710,6 +714,8 @@ class Trainer:
             for step, batch in enumerate(train_loader):
                 content_imgs = batch['content_image'].to(self.device, non_blocking=True).contiguous()
                 style_imgs = batch['style_image'].to(self.device, non_blocking=True).contiguous()
+                if self.gpu_augment is not None:
+                    content_imgs, style_imgs = self.gpu_augment[0](content_imgs), self.gpu_augment[1](style_imgs)
                 losses = run_step(content_imgs, style_imgs)
                 completed_step += step                                          # trainer.py:475 (sic: index, not 1)
                 row = torch.stack([l.detach().reshape(()) for l in losses])

@@ -99,14 +99,18 @@ class RandomRotation:
         self.degrees = (-float(degrees), float(degrees))
 
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
-        angle = float(torch.empty(1).uniform_(self.degrees[0], self.degrees[1]).item())
-        c, h, w = img.shape
-        a = math.radians(angle)
-        # inverse map output -> input in pixel units about the centre, then to normalised coords
-        cos, sin = math.cos(a), math.sin(a)
-        theta = torch.tensor([[cos, sin * h / w, 0.0], [-sin * w / h, cos, 0.0]], dtype=img.dtype).unsqueeze(0)
-        grid = F.affine_grid(theta, (1, c, h, w), align_corners=False)
-        return F.grid_sample(img.unsqueeze(0), grid, mode="nearest", padding_mode="zeros", align_corners=False)[0]
+        return rotate(img, float(torch.empty(1).uniform_(self.degrees[0], self.degrees[1]).item()))
+
+
+def rotate(img: torch.Tensor, angle: float) -> torch.Tensor:
+    """Rotation of a CHW tensor by ``angle`` degrees about the centre: nearest, same canvas, zero fill."""
+    c, h, w = img.shape
+    a = math.radians(angle)
+    # inverse map output -> input in pixel units about the centre, then to normalised coords
+    cos, sin = math.cos(a), math.sin(a)
+    theta = torch.tensor([[cos, sin * h / w, 0.0], [-sin * w / h, cos, 0.0]], dtype=img.dtype).unsqueeze(0)
+    grid = F.affine_grid(theta, (1, c, h, w), align_corners=False)
+    return F.grid_sample(img.unsqueeze(0), grid, mode="nearest", padding_mode="zeros", align_corners=False)[0]
 
 
 def _gray(img: torch.Tensor) -> torch.Tensor:
@@ -182,18 +186,24 @@ class ColorJitter:
         order = torch.randperm(4)
         u = lambda rng: None if rng is None else float(torch.empty(1).uniform_(rng[0], rng[1]))
         b, c, s, h = u(self.brightness), u(self.contrast), u(self.saturation), u(self.hue)
-        for fn in order.tolist():
-            if fn == 0 and b is not None:
-                img = _blend(img, torch.zeros_like(img), b)
-            elif fn == 1 and c is not None:
-                img = _blend(img, _gray(img).mean(), c)
-            elif fn == 2 and s is not None:
-                img = _blend(img, _gray(img).expand_as(img), s)
-            elif fn == 3 and h is not None:
-                hsv = _rgb2hsv(img)
-                hsv[0] = (hsv[0] + h) % 1.0
-                img = _hsv2rgb(hsv)
-        return img
+        return color_jitter(img, order.tolist(), b, c, s, h)
+
+
+def color_jitter(img: torch.Tensor, order, b=None, c=None, s=None, h=None) -> torch.Tensor:
+    """ColorJitter with its draws made explicit: ``order`` = permutation of (0 brightness, 1 contrast, 2 saturation,
+    3 hue), factors b / c / s and hue shift h (None = that adjustment is off)."""
+    for fn in order:
+        if fn == 0 and b is not None:
+            img = _blend(img, torch.zeros_like(img), b)
+        elif fn == 1 and c is not None:
+            img = _blend(img, _gray(img).mean(), c)
+        elif fn == 2 and s is not None:
+            img = _blend(img, _gray(img).expand_as(img), s)
+        elif fn == 3 and h is not None:
+            hsv = _rgb2hsv(img)
+            hsv[0] = (hsv[0] + h) % 1.0
+            img = _hsv2rgb(hsv)
+    return img
 
 
 class RandomHorizontalFlip:
@@ -212,14 +222,20 @@ class AddGaussianNoise:
 
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
         if np.random.rand() < self.p:
-            arr = img.squeeze().permute(1, 2, 0).detach().cpu().numpy()
-            arr = np.interp(arr, (arr.min(), arr.max()), (0, 1))
-            h, w, c = arr.shape
+            c, h, w = img.squeeze().shape
             sigma = np.random.uniform(*self.sigma_range)
-            noisy = arr + np.random.normal(self.mean, sigma, (h, w, c))
-            noisy = np.interp(noisy, (noisy.min(), noisy.max()), (0, 255)).astype(np.uint8)
-            return ToTensor()(noisy)
+            return add_noise(img, np.random.normal(self.mean, sigma, (h, w, c)))
         return img
+
+
+def add_noise(img: torch.Tensor, noise_hwc: np.ndarray) -> torch.Tensor:
+    """AddGaussianNoise with its noise field made explicit (HWC): min-max to [0, 1], add, min-max to [0, 255],
+    truncate to uint8, back to a [0, 1] tensor."""
+    arr = img.squeeze().permute(1, 2, 0).detach().cpu().numpy()
+    arr = np.interp(arr, (arr.min(), arr.max()), (0, 1))
+    noisy = arr + noise_hwc
+    noisy = np.interp(noisy, (noisy.min(), noisy.max()), (0, 255)).astype(np.uint8)
+    return ToTensor()(noisy)
 
 
 class RGBToGrayscaleStacked:
