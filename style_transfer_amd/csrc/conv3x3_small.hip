@@ -29,7 +29,10 @@ constexpr int KC = 8;
 // broadcast ds_read_b128 (every lane the same address); a thread owns TWO pixels (rows r and r+8 of a
 // 16 x 32 tile) so that each weight read feeds two FMAs and the LDS pipe stays at half load.
 // (Wave-uniform global loads would be the natural form, but the compiler turns 27 x 16 of them into
-// vector loads + v_readlane and spills SGPRs.)
+// vector loads + v_readlane and spills SGPRs.)  The kernel is bound by those LDS reads (a broadcast ds_read_b128
+// still returns 1 KB to the wave; 432 per thread, the LDS pipe is shared by four SIMDs): 3.5-4.0 TB/s of output.
+// A four-pixels-per-thread form with packed FMAs (half the LDS reads per FMA, 1 KB stores) was tried in round 2:
+// hipcc spills it (hoisted operand splats), so this form stays.
 constexpr int ACO = 64;      // output channels held in the LDS weight image
 
 template <int CIN>
@@ -115,12 +118,21 @@ constexpr int BHR = BTH + 2, BHC = BTW + 2;       // halo
 constexpr int BLD = 68;                           // LDS row stride (floats): 16-B aligned rows
 constexpr int BNP = (BHR * BHC + 255) / 256;      // halo positions per thread
 
+// forward tile (the weight-gradient kernel below keeps the 16 x 64 tile of BTH / BTW)
+constexpr int FTW = 128;                          // tile width
+constexpr int RPT = 1;                            // output rows per thread (a thread = RPT rows x 4 pixels x CO channels)
+constexpr int FKC = 8;                            // input channels staged per chunk
+constexpr int FTH = RPT * (1024 / FTW);
+constexpr int FHR = FTH + 2, FHC = FTW + 2;
+constexpr int FLD = FTW + 4;
+constexpr int FNP = (FHR * FHC + 255) / 256;
+
 template <int CO>
 __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, int cin, int H, int W, int cout_pad, int pad_zero, int relu,
     int tiles_x, int tiles_y) {
-  __shared__ __attribute__((aligned(16))) float xs[KC * BHR * BLD];
+  __shared__ __attribute__((aligned(16))) float xs[FKC * FHR * FLD];
   extern __shared__ __attribute__((aligned(16))) float wsm[];     // [cin * 9][4]: (co 0..2, pad) per (channel, tap)
   int bt = blockIdx.x;
   const int tx = bt % tiles_x;
@@ -128,21 +140,21 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(
   const int ty = bt % tiles_y;
   const int b = bt / tiles_y;
   const int tid = threadIdx.x;
-  const int x0 = tx * BTW, y0 = ty * BTH;
+  const int x0 = tx * FTW, y0 = ty * FTH;
   const size_t plane = size_t(H) * W;
   const float* xb = x + size_t(b) * cin * plane;
 
   // staging positions of this thread (source offset inside a plane, LDS offset, zero-pad mask)
-  unsigned soff[BNP], loff[BNP], smask[BNP];
+  unsigned soff[FNP], loff[FNP], smask[FNP];
 #pragma unroll
-  for (int i = 0; i < BNP; ++i) {
-    const int idx = min(tid + i * 256, BHR * BHC - 1);
-    const int r = idx / BHC, cc = idx - r * BHC;
+  for (int i = 0; i < FNP; ++i) {
+    const int idx = min(tid + i * 256, FHR * FHC - 1);
+    const int r = idx / FHC, cc = idx - r * FHC;
     const int gy = y0 + r - 1, gx = x0 + cc - 1;
     const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
     const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
     soff[i] = unsigned(cy) * unsigned(W) + unsigned(cx);
-    loff[i] = unsigned(r * BLD + cc);
+    loff[i] = unsigned(r * FLD + cc);
     smask[i] = (inb || !pad_zero) ? 0xffffffffu : 0u;
   }
 
@@ -151,71 +163,251 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(
     const int c = ct / 9, tap = ct - c * 9;
     wsm[i] = o < CO ? wp[size_t(((c / KC) * 9 + tap) * KC + (c % KC)) * cout_pad + o] : 0.f;
   }
-  const int row = tid >> 4, col4 = (tid & 15) * 4;    // 16 rows x 16 groups of 4 pixels
-  float acc[CO][4];
+  const int row = (tid / (FTW / 4)) * RPT, col4 = (tid % (FTW / 4)) * 4;
+  float acc[RPT][CO][4];
 #pragma unroll
-  for (int o = 0; o < CO; ++o)
+  for (int r = 0; r < RPT; ++r)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[o][q] = bias ? bias[o] : 0.f;
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[r][o][q] = bias ? bias[o] : 0.f;
 
-  const int nchunks = cin / KC;
+  // Software pipeline: the global loads of chunk k+1 are issued right after chunk k has been written to LDS and
+  // stay in flight under chunk k's FMAs (the staging registers are free by then).
+  const int nchunks = cin / FKC;
+  float st_[FKC][FNP];
+#pragma unroll
+  for (int c = 0; c < FKC; ++c)
+#pragma unroll
+    for (int i = 0; i < FNP; ++i) st_[c][i] = xb[size_t(c) * plane + soff[i]];
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    float st_[KC][BNP];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const float* src = xb + size_t(chunk * KC + c) * plane;
-#pragma unroll
-      for (int i = 0; i < BNP; ++i) st_[c][i] = src[soff[i]];
-    }
     __syncthreads();                                  // previous chunk's reads are done
+    // positions past the halo's end were clamped onto its last element: those threads store that element again
 #pragma unroll
-    for (int c = 0; c < KC; ++c)
+    for (int c = 0; c < FKC; ++c)
 #pragma unroll
-      for (int i = 0; i < BNP; ++i)
-        if (BHR * BHC % 256 == 0 || tid + i * 256 < BHR * BHC)
-          xs[c * (BHR * BLD) + loff[i]] = __uint_as_float(__float_as_uint(st_[c][i]) & smask[i]);
+      for (int i = 0; i < FNP; ++i)
+        xs[c * (FHR * FLD) + loff[i]] = __uint_as_float(__float_as_uint(st_[c][i]) & smask[i]);
     __syncthreads();
+    if (chunk + 1 < nchunks) {
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      float v[3][6];
+      for (int c = 0; c < FKC; ++c) {
+        const float* src = xb + size_t((chunk + 1) * FKC + c) * plane;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const float* rp = xs + c * (BHR * BLD) + (row + dy) * BLD + col4;
+        for (int i = 0; i < FNP; ++i) st_[c][i] = src[soff[i]];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < FKC; ++c) {
+      float v[RPT + 2][6];
+#pragma unroll
+      for (int dy = 0; dy < RPT + 2; ++dy) {
+        const float* rp = xs + c * (FHR * FLD) + (row + dy) * FLD + col4;
         const float4 a = *reinterpret_cast<const float4*>(rp);
         const float2 e = *reinterpret_cast<const float2*>(rp + 4);
         v[dy][0] = a.x; v[dy][1] = a.y; v[dy][2] = a.z; v[dy][3] = a.w; v[dy][4] = e.x; v[dy][5] = e.y;
       }
+      const int ch = chunk * FKC + c;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wsm + ((chunk * KC + c) * 9 + tap) * 4);   // broadcast
+        const float4 w4 = *reinterpret_cast<const float4*>(wsm + (ch * 9 + tap) * 4);   // broadcast
         const float wr[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int o = 0; o < CO; ++o) {
-          const float wv = wr[o];
+        for (int r = 0; r < RPT; ++r)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[o][q] = fmaf(wv, v[tap / 3][q + tap % 3], acc[o][q]);
-        }
+          for (int o = 0; o < CO; ++o) {
+            const float wv = wr[o];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][o][q] = fmaf(wv, v[r + tap / 3][q + tap % 3], acc[r][o][q]);
+          }
       }
     }
   }
 
-  const int oy = y0 + row, ox = x0 + col4;
-  if (oy < H && ox < W) {
+  const int ox = x0 + col4;
 #pragma unroll
-    for (int o = 0; o < CO; ++o) {
-      float* dst = y + (size_t(b) * CO + o) * plane + size_t(oy) * W + ox;
-      float r[4];
+  for (int r = 0; r < RPT; ++r) {
+    const int oy = y0 + row + r;
+    if (oy < H && ox < W) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) r[q] = relu ? fmaxf(acc[o][q], 0.f) : acc[o][q];
-      if (ox + 3 < W && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-        *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
-      } else {
+      for (int o = 0; o < CO; ++o) {
+        float* dst = y + (size_t(b) * CO + o) * plane + size_t(oy) * W + ox;
+        float rr[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (ox + q < W) dst[q] = r[q];
+        for (int q = 0; q < 4; ++q) rr[q] = relu ? fmaxf(acc[r][o][q], 0.f) : acc[r][o][q];
+        if (ox + 3 < W && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (ox + q < W) dst[q] = rr[q];
+        }
       }
     }
   }
+}
+
+// ---- cout <= 4, row-strip form (W % 4 == 0, 16-B aligned planes) -------------------------------------------
+// No LDS staging of the input at all: a group of LPR lanes owns a strip of SR output rows x LPR*4 pixels and walks
+// over the input channels; per channel it loads the SR + 2 input rows of its strip ONCE as aligned 16-B vectors
+// (the column to the left / right comes from the neighbouring lane; only the two lanes at the ends of a group load
+// a halo dword), and every loaded row feeds the (up to) three output rows it belongs to from registers.  The rows of
+// channel c + 1 are in flight while channel c is multiplied.  Weights: LDS, 9 broadcast reads per channel.
+typedef float sf4 __attribute__((ext_vector_type(4)));
+
+template <int SR>
+struct StripRows {
+  sf4 a[SR + 2];
+  float e[SR + 2];
+};
+
+template <int CO, int LPR, int SR, bool ZP>
+__global__ __launch_bounds__(256, (SR > 4 ? 2 : 3)) void conv3x3_cout_strip_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, int cin, int H, int W, int cout_pad, int relu,
+    int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];     // [cin * 9][4]: (co 0..2, pad) per (channel, tap)
+  constexpr int GROUPS = 256 / LPR;
+  int bt = blockIdx.x;
+  const int tx = bt % tiles_x;
+  bt /= tiles_x;
+  const int ty = bt % tiles_y;
+  const int b = bt / tiles_y;
+  const int tid = threadIdx.x;
+  const int g = tid / LPR, t = tid % LPR;
+  const size_t plane = size_t(H) * W;
+  const float* xb = x + size_t(b) * cin * plane;
+
+  for (int i = tid; i < cin * 9 * 4; i += 256) {
+    const int o = i & 3, ct = i >> 2;                  // ct = channel * 9 + tap
+    const int c = ct / 9, tap = ct - c * 9;
+    wsm[i] = o < CO ? wp[size_t(((c / KC) * 9 + tap) * KC + (c % KC)) * cout_pad + o] : 0.f;
+  }
+
+  const int y0 = (ty * GROUPS + g) * SR;               // first output row of this strip
+  const int colraw = (tx * LPR + t) * 4;
+  const bool live = colraw < W;
+  const int col = min(colraw, W - 4);                 // dead lanes shadow the last column group
+  const bool has_l = col > 0, has_r = col + 4 < W;
+  const bool edge_l = t == 0, edge_r = t == LPR - 1 || (tid & 63) == 63;
+  const bool eload = (edge_l && has_l) || (edge_r && has_r && !(edge_l && has_l));
+  const int eoff = (edge_l && has_l) ? col - 1 : col + 4;
+  // LPR == 1 would need both halos from memory; the host never picks it
+  unsigned roff[SR + 2];
+  float rmask[SR + 2];
+#pragma unroll
+  for (int i = 0; i < SR + 2; ++i) {
+    const int gy = y0 - 1 + i;
+    roff[i] = unsigned(min(max(gy, 0), H - 1)) * unsigned(W);
+    rmask[i] = (ZP && (gy < 0 || gy >= H)) ? 0.f : 1.f;
+  }
+
+  float acc[SR][CO][4];
+  float bv[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) bv[o] = bias ? bias[o] : 0.f;
+#pragma unroll
+  for (int r = 0; r < SR; ++r)
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[r][o][q] = bv[o];
+  __syncthreads();
+
+  // Rolling prefetch: as soon as row i of channel c has been multiplied, the same row of channel c + 1 is requested
+  // (the scheduling barriers keep the request there; hipcc otherwise sinks all of them below the FMAs).  hipcc loads
+  // into fresh registers and copies them at the loop's end behind a wait for everything, so a wave stalls once per
+  // channel for the tail of its requests; the other waves of the SIMD cover that.  (Tying the request to the row's
+  // own registers with "+v" asm operands does not survive register allocation: it copies registers with loads in
+  // flight.  Tried and removed.)  Buffer loads: 32-bit per-lane offsets, the channel offset is the scalar offset.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, int(unsigned(size_t(cin) * plane * sizeof(float))), 0x00020000);
+  const unsigned plane_bytes = unsigned(plane * sizeof(float));
+  const int edelta = eload ? (eoff - col) * 4 : 0;     // lanes without a halo column re-read their own first element
+  StripRows<SR> rw;
+#pragma unroll
+  for (int i = 0; i < SR + 2; ++i) {
+    const int vo = int((roff[i] + unsigned(col)) * 4u);
+    rw.a[i] = __builtin_bit_cast(sf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0));
+    rw.e[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo + edelta, 0, 0));
+  }
+  for (int ch = 0; ch < cin; ++ch) {
+    float wv[9][CO];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float4 w4 = *reinterpret_cast<const float4*>(wsm + (ch * 9 + tap) * 4);   // broadcast
+      const float wr[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int o = 0; o < CO; ++o) wv[tap][o] = wr[o];
+    }
+    const int so = int(unsigned(min(ch + 1, cin - 1)) * plane_bytes);    // the last channel re-reads itself (unused)
+#pragma unroll
+    for (int i = 0; i < SR + 2; ++i) {
+      sf4 a = rw.a[i];
+      float e = rw.e[i];
+      if (ZP) { a = a * rmask[i]; e = e * rmask[i]; }
+      const float nl = __shfl_up(a[3], 1, 64), nr = __shfl_down(a[0], 1, 64);
+      float v[6];
+      v[0] = !has_l ? (ZP ? 0.f : a[0]) : (edge_l ? e : nl);
+      v[1] = a[0]; v[2] = a[1]; v[3] = a[2]; v[4] = a[3];
+      v[5] = !has_r ? (ZP ? 0.f : a[3]) : (edge_r ? e : nr);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int r = i - dy;
+        if (r < 0 || r >= SR) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int o = 0; o < CO; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][o][q] = fmaf(wv[dy * 3 + dx][o], v[q + dx], acc[r][o][q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int vo = int((roff[i] + unsigned(col)) * 4u);
+      rw.a[i] = __builtin_bit_cast(sf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, so, 0));
+      rw.e[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo + edelta, so, 0));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+      const int oy = y0 + r;
+      if (oy < H) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+          sf4 out;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out[q] = relu ? fmaxf(acc[r][o][q], 0.f) : acc[r][o][q];
+          *reinterpret_cast<sf4*>(y + (size_t(b) * CO + o) * plane + size_t(oy) * W + col) = out;
+        }
+      }
+    }
+  }
+}
+
+template <int LPR, int SR>
+int launch_cout_strip(const float* x, const float* wp, const float* bias, float* y, int n, int cin, int h, int w,
+                      int cout_pad, int pad_zero, int relu, hipStream_t s) {
+  const int tiles_x = st::cdiv(w, LPR * 4), tiles_y = st::cdiv(h, (256 / LPR) * SR);
+  const dim3 grid((unsigned)(n * tiles_x * tiles_y));
+  const size_t lds = size_t(cin) * 9 * 4 * sizeof(float);
+  if (pad_zero)
+    hipLaunchKernelGGL((conv3x3_cout_strip_kernel<3, LPR, SR, true>), grid, dim3(256), lds, s, x, wp, bias, y, cin, h,
+                       w, cout_pad, relu, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL((conv3x3_cout_strip_kernel<3, LPR, SR, false>), grid, dim3(256), lds, s, x, wp, bias, y, cin, h,
+                       w, cout_pad, relu, tiles_x, tiles_y);
+  return st::check_launch("st_conv3x3_fwd(cout=3, strips)");
+}
+
+template <int SR>
+int launch_cout_strip_w(const float* x, const float* wp, const float* bias, float* y, int n, int cin, int h, int w,
+                        int cout_pad, int pad_zero, int relu, hipStream_t s) {
+  if (w >= 256) return launch_cout_strip<64, SR>(x, wp, bias, y, n, cin, h, w, cout_pad, pad_zero, relu, s);
+  if (w >= 128) return launch_cout_strip<32, SR>(x, wp, bias, y, n, cin, h, w, cout_pad, pad_zero, relu, s);
+  return launch_cout_strip<16, SR>(x, wp, bias, y, n, cin, h, w, cout_pad, pad_zero, relu, s);
 }
 
 // ---- weight / bias gradient of a layer with cout == 3 (the decoder's last conv) ------------
@@ -363,8 +555,20 @@ bool conv3x3_small_fwd(const float* x, const float* w_packed, const float* bias,
     *rc = check_launch("st_conv3x3_fwd(cin=3)");
     return true;
   }
-  if (cout == 3 && cin % KC == 0 && cin <= 512) {
-    const int tiles_x = cdiv(w, BTW), tiles_y = cdiv(h, BTH);
+  // Row-strip kernel (w % 4 == 0, 16-B aligned, one image below 4 GB): 8-row strips when they make at least two
+  // waves per SIMD (2 M pixels), 2-row strips down to 256 K pixels (B=8 at 256 x 256: 55 us against 58 us), the
+  // LDS-tiled kernel below that and for every other shape.
+  const long long pixels = (long long)n * h * w;
+  if (cout == 3 && cin % KC == 0 && cin <= 512 && cout_pad >= 4 && w % 4 == 0 && w >= 64 &&
+      reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+      (long long)cin * h * w * 4 < (1LL << 32) && (long long)n * cdiv(w, 64) * cdiv(h, 8) < 0x7fffffffLL &&
+      pixels >= (1 << 18)) {
+    if (pixels >= (1 << 21)) *rc = launch_cout_strip_w<8>(x, w_packed, bias, y, n, cin, h, w, cout_pad, pad_zero, relu, s);
+    else *rc = launch_cout_strip_w<2>(x, w_packed, bias, y, n, cin, h, w, cout_pad, pad_zero, relu, s);
+    return true;
+  }
+  if (cout == 3 && cin % KC == 0 && cin <= 512 && cout_pad >= 4) {
+    const int tiles_x = cdiv(w, FTW), tiles_y = cdiv(h, FTH);
     const long long blocks = (long long)n * tiles_x * tiles_y;
     if (blocks > 0x7fffffffLL) return false;
     hipLaunchKernelGGL(conv3x3_cout_small_kernel<3>, dim3((unsigned)blocks), dim3(256), size_t(cin) * 9 * 4 * sizeof(float),

@@ -45,6 +45,15 @@ def ops():
     (1, 128, 3, 33, 130, False, "replicate", False),   # 16 chunks, three column tiles
     (1, 8, 3, 1, 1, False, "replicate", False),
     (1, 12, 3, 5, 5, False, "replicate", False),       # cin % 8 != 0 -> MFMA kernel
+    # w % 4 == 0, w >= 64 and >= 256 K pixels: the row-strip kernel (2-row strips; 8-row strips from 2 M pixels) with
+    # 16 / 32 / 64 lanes per row, a ragged last column tile, strips that overhang the image, both pads
+    (4, 8, 3, 964, 68, False, "zero", True),
+    (2, 8, 3, 1000, 132, False, "replicate", False),
+    (4, 16, 3, 255, 260, False, "replicate", True),
+    (1, 8, 3, 513, 512, False, "zero", False),
+    (8, 8, 3, 4001, 68, False, "replicate", False),
+    (1, 8, 3, 1030, 2048, False, "zero", True),
+    (3, 24, 3, 1021, 700, False, "replicate", False),
 ])
 def test_conv3x3(ops, n, cin, cout, h, w, up, pad, relu):
     g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
