@@ -264,10 +264,12 @@ int st_meanstd_loss_bwd(const float* x, const float* mean_a, const float* std_a,
                         int hw, int accumulate, st_stream_t stream);
 
 /* ---- RGB-uv histogram (RGBuvHistBlock.forward, losses.py:169-322; 'interpolation' resizing,
- * green_only = False, h = 64) and the Hellinger distance of HistLoss (losses.py:338-347) -------
+ * all three pairings, h <= 64) and the Hellinger distance of HistLoss (losses.py:338-347) -------
  *   x:      [n][c>=3][h][w] (first three channels are used, losses.py:192-193)
  *   hist:   [n][3][64][64] normalised (each image sums to 1); totals: [n] un-normalised sums
- *   bins_host: HOST array of nbins (= 64) float64 bin centres, np.linspace(lo, hi, 64)
+ *   bins_host: HOST array of nbins (1..64) float64 bin centres, np.linspace(lo, hi, nbins); with nbins < 64 the
+ *           histogram occupies hist[n][k][:nbins][:nbins] and the rest of each 64 x 64 plane is zero
+ *           ('sampling' resizing and green_only are host-side selections around this call: losses.RGBuvHistBlock)
  *   method: ST_HIST_*; sigma as in losses.py:124; insz: resize threshold/size (HistLoss: 128)
  * In ST_HIST_THRESHOLDING with intensity_scale = 0 the un-normalised bins are exact integer
  * counts (no atomics, exact fp32 sums).  workspace: st_rgbuv_hist_workspace_bytes(). */

@@ -53,15 +53,50 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+def hist_options(L, out_dir):
+    """RGBuvHistBlock with the settings HistLoss never uses (losses.py:175-183 'sampling', :195-196 / :278-281
+    green_only, h != 64): outputs of the reference's module on seeded inputs."""
+    ho = {}
+    gh = torch.Generator().manual_seed(44)
+    small = torch.rand(2, 3, 24, 20, generator=gh) * 1.4 - 0.2
+    big = torch.rand(2, 3, 150, 141, generator=gh)
+    ho["small"], ho["big"] = _np(small), _np(big)
+    cases = [("h32_iq", dict(h=32, method="inverse-quadratic")), ("h32_rbf", dict(h=32, method="RBF")),
+             ("h32_thr", dict(h=32, method="thresholding", intensity_scale=False)),
+             ("h48_iq", dict(h=48, method="inverse-quadratic", hist_boundary=[-2, 2.5])),
+             ("green_iq", dict(h=64, method="inverse-quadratic", green_only=True)),
+             ("green_thr16", dict(h=16, method="thresholding", green_only=True)),
+             ("samp_iq", dict(h=64, method="inverse-quadratic", resizing="sampling")),
+             ("samp_green32", dict(h=32, method="RBF", resizing="sampling", green_only=True))]
+    for tag, kw in cases:
+        blk = L.RGBuvHistBlock(insz=128, device="cpu", **kw)
+        with torch.no_grad():
+            ho[f"{tag}_small"] = _np(blk(small))
+            ho[f"{tag}_big"] = _np(blk(big))
+    # gradient through one of them (autograd of the reference)
+    blk = L.RGBuvHistBlock(insz=128, device="cpu", h=32, method="inverse-quadratic", green_only=True, resizing="sampling")
+    wgt = torch.rand(2, 1, 32, 32, generator=gh)
+    xb = big.clone().requires_grad_(True)
+    (blk(xb) * wgt).sum().backward()
+    ho["grad_w"], ho["grad_dbig"] = _np(wgt), _np(xb.grad)
+    np.savez_compressed(os.path.join(out_dir, "hist_options.npz"), **ho)
+    print("hist_options.npz", os.path.getsize(os.path.join(out_dir, "hist_options.npz")), "bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default=None, choices=[None, "hist_options"],
+                    help="write just this file (added in round 2; the others stay as generated in round 1)")
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
     G, T, L = _import_reference(args.ref)
     torch.set_num_threads(8)
+    if args.only == "hist_options":
+        hist_options(L, out_dir)
+        return
 
     # ---- 1. SymmetricPadding2D ------------------------------------------------
     x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)

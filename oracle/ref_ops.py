@@ -383,15 +383,22 @@ class hist_kernel_dtype:
 
 def rgbuv_hist(x: torch.Tensor, h: int = 64, insz: int = 128, method: str = "inverse-quadratic",
                sigma: float = 0.02, intensity_scale: bool = True,
-               hist_boundary=(-3.0, 3.0)) -> torch.Tensor:
-    """RGBuvHistBlock.forward (losses.py:169-322), 'interpolation' resizing,
-    green_only=False.  Bin centres are float64 (np.linspace, losses.py:211-213),
+               hist_boundary=(-3.0, 3.0), resizing: str = "interpolation", green_only: bool = False) -> torch.Tensor:
+    """RGBuvHistBlock.forward (losses.py:169-322).  Bin centres are float64 (np.linspace, losses.py:211-213),
     so the kernel weights are evaluated in float64 and cast to float32
-    (losses.py:239-240) before the [h,N]x[N,h] product."""
+    (losses.py:239-240) before the [h,N]x[N,h] product.  'sampling' picks h (sic: the bin count, losses.py:176-181)
+    rows and columns; green_only keeps the G pairing alone (losses.py:195-196, 278-281)."""
     lo, hi = sorted(hist_boundary)
     x = torch.clamp(x, 0, 1)
     if x.shape[2] > insz or x.shape[3] > insz:
-        x = F.interpolate(x, size=(insz, insz), mode="bilinear", align_corners=False)
+        if resizing == "interpolation":
+            x = F.interpolate(x, size=(insz, insz), mode="bilinear", align_corners=False)
+        elif resizing == "sampling":
+            i1 = torch.LongTensor(np.linspace(0, x.shape[2], h, endpoint=False))
+            i2 = torch.LongTensor(np.linspace(0, x.shape[3], h, endpoint=False))
+            x = x.index_select(2, i1).index_select(3, i2)
+        else:
+            raise Exception(f"Wrong resizing method {resizing}")
     if x.shape[1] > 3:
         x = x[:, :3]
     bins = torch.tensor(np.linspace(lo, hi, num=h)).unsqueeze(0)       # float64 [1,h]
@@ -405,7 +412,7 @@ def rgbuv_hist(x: torch.Tensor, h: int = 64, insz: int = 128, method: str = "inv
             Iy = 1
         logI = torch.log(I + HIST_EPS)
         per_ch = []
-        for ch in range(3):
+        for ch in ((1,) if green_only else range(3)):
             others = [o for o in range(3) if o != ch]
             Iu = (logI[:, ch] - logI[:, others[0]]).unsqueeze(1)
             Iv = (logI[:, ch] - logI[:, others[1]]).unsqueeze(1)

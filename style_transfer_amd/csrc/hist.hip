@@ -450,12 +450,15 @@ size_t rec_elems(int n, int N) { return std::max(size_t(n) * NREC * N, size_t(n)
 int fill_params(HistParams& hp, int method, float sigma, const double* bins_host, int nbins,
                 int intensity_scale, const char* who) {
   ST_REQUIRE(bins_host, "%s: null bins", who);
-  ST_REQUIRE(nbins == HB, "%s: only h = %d bins is supported (HistLoss default), got %d", who, HB, nbins);
+  ST_REQUIRE(nbins >= 1 && nbins <= HB, "%s: 1 <= h <= %d bins are supported (HistLoss uses %d), got %d", who, HB, HB,
+             nbins);
   ST_REQUIRE(method >= ST_HIST_INVERSE_QUADRATIC && method <= ST_HIST_THRESHOLDING, "%s: bad method %d", who,
              method);
-  for (int i = 0; i < HB; ++i) hp.bins[i] = bins_host[i];
+  // h < 64: the kernels always work on 64 x 64 bins; the unused centres sit at 1e30, where every kernel weight and
+  // its derivative evaluate to exactly 0, so rows / columns >= h of the output are zero and the totals see nothing
+  for (int i = 0; i < HB; ++i) hp.bins[i] = i < nbins ? bins_host[i] : 1e30;
   // losses.py:164-165: eps = (|lo| + |hi|) / h, membership is |d| <= eps / 2
-  hp.thr = (fabs(bins_host[0]) + fabs(bins_host[HB - 1])) / double(HB) / 2.0;
+  hp.thr = (fabs(bins_host[0]) + fabs(bins_host[nbins - 1])) / double(nbins) / 2.0;
   hp.inv_sigma2 = 1.0 / (double(sigma) * double(sigma));
   hp.method = method;
   hp.intensity_scale = intensity_scale ? 1 : 0;

@@ -161,10 +161,11 @@ class _RGBuvHistFunction(torch.autograd.Function):
                                          _lib.stream_ptr()), "st_rgbuv_hist_fwd")
         ctx.cfg = (insz, method, sigma, tuple(bins), intensity_scale)
         ctx.save_for_backward(x, hist, totals)
-        return hist
+        ctx.mark_non_differentiable(totals)
+        return hist, totals                 # totals: un-normalised per-image sums (a constant for autograd)
 
     @staticmethod
-    def backward(ctx, ghist):
+    def backward(ctx, ghist, _gtotals=None):
         import ctypes
         x, hist, totals = ctx.saved_tensors
         insz, method, sigma, bins, intensity_scale = ctx.cfg
@@ -183,8 +184,11 @@ class _RGBuvHistFunction(torch.autograd.Function):
 
 
 class RGBuvHistBlock(nn.Module):
-    """losses.py:122-322.  Supported on the HIP path: h=64, resizing='interpolation',
-    green_only=False (the configuration HistLoss builds, losses.py:333-336); other settings raise."""
+    """losses.py:122-322 on the HIP histogram kernels (csrc/hist.hip).  HistLoss builds h=64, 'interpolation', all
+    three pairings (losses.py:333-336); the other settings of the reference's block are served around the same
+    kernels: h < 64 (the kernels' 64 x 64 bins with the unused centres parked where every weight is 0, sliced
+    here), green_only (the G pairing's plane, re-normalised by its own sum, losses.py:195-196, 278-281, 319-320)
+    and resizing='sampling' (h -- sic -- rows and columns picked by index, losses.py:175-183).  h > 64 raises."""
 
     def __init__(self, h=64, insz=150, resizing='interpolation', method='inverse-quadratic', sigma=0.02,
                  intensity_scale=True, hist_boundary=None, green_only=False, device='cuda'):
@@ -203,8 +207,8 @@ class RGBuvHistBlock(nn.Module):
         if self.method == 'thresholding':
             self.eps = (abs(hist_boundary[0]) + abs(hist_boundary[1])) / h
         self.sigma = sigma
-        if h != 64 or green_only or resizing != 'interpolation':
-            raise NotImplementedError("HIP RGBuvHistBlock supports h=64, green_only=False, resizing='interpolation'")
+        if not 1 <= h <= 64:
+            raise NotImplementedError("HIP RGBuvHistBlock supports 1 <= h <= 64 bins")
         if method not in _HIST_METHODS:
             raise Exception(f'Wrong kernel method. It should be either thresholding, RBF,'
                             f' inverse-quadratic. But the given value is {self.method}.')
@@ -212,8 +216,29 @@ class RGBuvHistBlock(nn.Module):
         self._bins = [float(v) for v in np.linspace(self.hist_boundary[0], self.hist_boundary[1], num=self.h)]
 
     def forward(self, x):
-        return _RGBuvHistFunction.apply(x.contiguous(), int(self.insz), _HIST_METHODS[self.method], float(self.sigma),
-                                        self._bins, bool(self.intensity_scale))
+        insz = int(self.insz)
+        if x.shape[2] > insz or x.shape[3] > insz:
+            if self.resizing == 'sampling':
+                # clamp (inside the kernel) and index selection commute; the picked image is never resized again
+                i1 = torch.as_tensor(np.linspace(0, x.shape[2], self.h, endpoint=False).astype(np.int64), device=x.device)
+                i2 = torch.as_tensor(np.linspace(0, x.shape[3], self.h, endpoint=False).astype(np.int64), device=x.device)
+                x = x.index_select(2, i1).index_select(3, i2)
+                insz = max(insz, self.h)
+            elif self.resizing != 'interpolation':
+                raise Exception(f'Wrong resizing method. It should be: interpolation or sampling. '
+                                f'But the given value is {self.resizing}.')
+        hist, totals = _RGBuvHistFunction.apply(x.contiguous(), insz, _HIST_METHODS[self.method], float(self.sigma),
+                                                self._bins, bool(self.intensity_scale))
+        if self.h < 64:
+            hist = hist[:, :, :self.h, :self.h]
+        if self.green_only:
+            # The kernels normalise by T + EPS, T = the sum over all three pairings.  The G plane normalised by its
+            # own un-normalised sum S_g is raw_g / (S_g + EPS) = hist_g / (sum(hist_g) + EPS / (T + EPS))
+            # (losses.py:319-320); T is a constant for autograd, which touches the derivative only through that
+            # EPS term (1e-6 / T, T in the thousands).
+            g = hist[:, 1:2]
+            hist = g / (g.sum(dim=(1, 2, 3), keepdim=True) + EPS / (totals.view(-1, 1, 1, 1) + EPS))
+        return hist
 
 
 class _HellingerSqFunction(torch.autograd.Function):

@@ -126,3 +126,58 @@ def test_hist_loss_known_answer(golden_dir):
     tgt = torch.rand(8, 3, 256, 256)
     v = HistLoss()(img.cuda(), tgt.cuda())
     assert float(v) == pytest.approx(float(kat["histloss"]), rel=1e-4)       # 2.91424...
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+HIST_OPTION_CASES = {
+    "h32_iq": dict(h=32, method="inverse-quadratic"), "h32_rbf": dict(h=32, method="RBF"),
+    "h32_thr": dict(h=32, method="thresholding", intensity_scale=False),
+    "h48_iq": dict(h=48, method="inverse-quadratic", hist_boundary=[-2, 2.5]),
+    "green_iq": dict(h=64, method="inverse-quadratic", green_only=True),
+    "green_thr16": dict(h=16, method="thresholding", green_only=True),
+    "samp_iq": dict(h=64, method="inverse-quadratic", resizing="sampling"),
+    "samp_green32": dict(h=32, method="RBF", resizing="sampling", green_only=True),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(HIST_OPTION_CASES))
+def test_hist_block_options_against_reference_golden(golden_dir, tag):
+    """The settings HistLoss never uses -- h < 64, green_only, resizing='sampling' (losses.py:175-183, 195-196,
+    278-281) -- against the reference module's outputs (tests/golden/hist_options.npz)."""
+    from style_transfer_amd.losses import RGBuvHistBlock
+    g = np.load(os.path.join(golden_dir, "hist_options.npz"))
+    kw = dict(HIST_OPTION_CASES[tag])
+    if "hist_boundary" in kw:
+        kw["hist_boundary"] = list(kw["hist_boundary"])
+    blk = RGBuvHistBlock(insz=128, **kw)
+    for which in ("small", "big"):
+        with torch.no_grad():
+            got = blk(torch.from_numpy(g[which]).cuda()).cpu()
+        want = torch.from_numpy(g[f"{tag}_{which}"])
+        assert got.shape == want.shape
+        d = (got - want).abs()
+        if "thr" in tag:        # a pixel on a bin edge may fall either way (SURVEY H1): few bins, single-pixel moves
+            assert d.max() < 2e-2 and (d > 1e-6).sum() <= 8, (tag, which, float(d.max()), int((d > 1e-6).sum()))
+        else:
+            assert d.max() <= 1e-4 * want.abs().max() + 1e-7, (tag, which, float(d.max()))
+        torch.testing.assert_close(got.sum(dim=(1, 2, 3)), want.sum(dim=(1, 2, 3)), rtol=1e-5, atol=1e-6)
+
+
+def test_hist_block_options_gradient_against_reference_golden(golden_dir):
+    from style_transfer_amd.losses import RGBuvHistBlock
+    g = np.load(os.path.join(golden_dir, "hist_options.npz"))
+    blk = RGBuvHistBlock(insz=128, h=32, method="inverse-quadratic", green_only=True, resizing="sampling")
+    x = torch.from_numpy(g["big"]).cuda().requires_grad_(True)
+    (blk(x) * torch.from_numpy(g["grad_w"]).cuda()).sum().backward()
+    want = torch.from_numpy(g["grad_dbig"])
+    assert rel_l2(x.grad.cpu(), want) < 2e-3
+    assert ((x.grad.cpu() != 0) == (want != 0)).all()          # only the sampled pixels receive a gradient
+
+
+def test_hist_block_rejects_more_than_64_bins():
+    from style_transfer_amd.losses import RGBuvHistBlock
+    with pytest.raises(NotImplementedError):
+        RGBuvHistBlock(h=128)

@@ -161,3 +161,37 @@ def test_loss_vgg_capture_rule():
     assert float(f7.min()) < 0.0           # idx 7 is the last kept layer: pre-ReLU
     v = torch.randn(4, 3, 3, 3); gn = v.reshape(4, -1).norm(dim=1)
     _close(R.weight_norm_effective(v, gn), v.numpy(), rtol=1e-6)
+
+
+HIST_OPTION_CASES = {
+    "h32_iq": dict(h=32, method="inverse-quadratic"), "h32_rbf": dict(h=32, method="RBF"),
+    "h32_thr": dict(h=32, method="thresholding", intensity_scale=False),
+    "h48_iq": dict(h=48, method="inverse-quadratic", hist_boundary=[-2, 2.5]),
+    "green_iq": dict(h=64, method="inverse-quadratic", green_only=True),
+    "green_thr16": dict(h=16, method="thresholding", green_only=True),
+    "samp_iq": dict(h=64, method="inverse-quadratic", resizing="sampling"),
+    "samp_green32": dict(h=32, method="RBF", resizing="sampling", green_only=True),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(HIST_OPTION_CASES))
+def test_hist_block_options_match_the_reference(golden_dir, tag):
+    """RGBuvHistBlock's h != 64 / green_only / 'sampling' settings (losses.py:175-183, 195-196, 278-281) against
+    outputs of the reference's module (tests/golden/hist_options.npz, oracle/gen_golden.py --only hist_options)."""
+    g = _load(golden_dir, "hist_options.npz")
+    for which in ("small", "big"):
+        got = R.rgbuv_hist(torch.from_numpy(g[which]), insz=128, **HIST_OPTION_CASES[tag])
+        want = torch.from_numpy(g[f"{tag}_{which}"])
+        assert got.shape == want.shape
+        if "thr" in tag:       # a pixel on a bin edge may move between two fp32 evaluations of the same log
+            assert (got - want).abs().max() < 2e-2 and ((got - want).abs() > 1e-7).sum() <= 8
+        else:
+            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-7)
+
+
+def test_hist_block_options_gradient_matches_the_reference(golden_dir):
+    g = _load(golden_dir, "hist_options.npz")
+    x = torch.from_numpy(g["big"]).requires_grad_(True)
+    (R.rgbuv_hist(x, insz=128, h=32, method="inverse-quadratic", green_only=True, resizing="sampling")
+     * torch.from_numpy(g["grad_w"])).sum().backward()
+    torch.testing.assert_close(x.grad, torch.from_numpy(g["grad_dbig"]), rtol=1e-3, atol=1e-8)

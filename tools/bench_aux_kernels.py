@@ -28,6 +28,27 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3      # us
 
 
+def graphed(fn):
+    """fn captured in a HIP graph: the replay time is the GPU time of its kernels without the host's launch and
+    autograd overhead (what a training step replayed from graphs pays).  Falls back to fn if capture fails."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g.replay
+    except Exception as e:       # noqa: BLE001
+        print(f"   (graph capture failed: {type(e).__name__}: {e}; eager timing)", flush=True)
+        torch.cuda.synchronize()
+        return fn
+
+
 def line(name, us, nbytes=None, flops=None):
     s = f"{name:58s} {us:9.1f} us"
     if nbytes:
@@ -57,6 +78,7 @@ def main():
             xg.grad = None
             (hist.histogram_block(xg) * t).sum().backward()
         line(f"rgbuv_hist fwd+bwd  B={b} S={s}", timeit(fb), nbytes=4.0 * (3 * x.numel()))
+        line(f"rgbuv_hist fwd+bwd  B={b} S={s}  (graph replay)", timeit(graphed(fb)), nbytes=4.0 * (3 * x.numel()))
         with torch.no_grad():
             line(f"tv fwd  B={b} S={s}", timeit(lambda: tv(x)), nbytes=4.0 * x.numel())
             line(f"normalize fwd  B={b} S={s}", timeit(lambda: ops.normalize(x, [.485, .456, .406], [.229, .224, .225])),
@@ -77,12 +99,16 @@ def main():
             mu, cov = vin.calc_2_moments(fc)
             (cov * gc).sum().backward()
         line(f"covariance (Gram) fwd+bwd  [{b},{c},{hw},{hw}]", timeit(cb), flops=6.0 * b * c * c * hw * hw)
+        line(f"covariance (Gram) fwd+bwd  [{b},{c},{hw},{hw}]  (graph replay)", timeit(graphed(cb)),
+             flops=6.0 * b * c * c * hw * hw)
         fg = f.clone().requires_grad_(True)
 
         def sb():
             fg.grad = None
             sty(fg, f2).backward()
         line(f"mean/std style loss fwd+bwd  [{b},{c},{hw},{hw}]", timeit(sb), nbytes=4.0 * 4 * f.numel())
+        line(f"mean/std style loss fwd+bwd  [{b},{c},{hw},{hw}]  (graph replay)", timeit(graphed(sb)),
+             nbytes=4.0 * 4 * f.numel())
 
 
 if __name__ == "__main__":
