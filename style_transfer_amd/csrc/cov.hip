@@ -31,30 +31,21 @@ __device__ __forceinline__ void tri_tile(int idx, int tiles, int& ti, int& tj) {
   tj = row + left;
 }
 
-template <int T>
-__global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x,
-                                                    const float* __restrict__ mean,
-                                                    float* __restrict__ slabs, int B, int C, int n,
-                                                    int chunks_per_split) {
+// One T x T tile over the block's pixel range.  DIAG (both operands are the same rows: staged once) is a template
+// parameter: as a run-time condition around the second operand's loads it made hipcc keep both staging arrays in
+// SCRATCH behind a dynamic offset, with a wait and a scratch store after every global load.
+template <int T, bool DIAG>
+__device__ __forceinline__ void cov_tile(const float* __restrict__ xb, const float* __restrict__ mb,
+                                         float* __restrict__ slab, float* smem, int C, int n, int i0, int j0,
+                                         int c_begin, int c_end) {
   constexpr int MT = T / 64;
   constexpr int R = T / 4;      // rows each wave stages per operand
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xi = smem;
   float* Xj = smem + T * LSF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles = (C + T - 1) / T;
-  int ti, tj;
-  tri_tile(blockIdx.x, tiles, ti, tj);
-  const bool diag = ti == tj;                  // both operands are the same rows: stage them once
-  const int i0 = ti * T, j0 = tj * T;
-  const int split = blockIdx.y, b = blockIdx.z;
-  const float* xb = x + (size_t)b * C * n;
-  const float* mb = mean + (size_t)b * C;
-  const int nchunks = (n + KN - 1) / KN;
-  const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, nchunks);
-  const float* Xjr = diag ? Xi : Xj;
+  const float* Xjr = DIAG ? Xi : Xj;
 
   f32x16 acc[MT][MT];
 #pragma unroll
@@ -64,24 +55,31 @@ __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[a][c][k] = 0.f;
 
-  // per-row constants of this wave's staging rows (wave w stages rows w, w+4, ...; lane = pixel of the chunk)
-  float mi[R], mj[R];
-  const float* ri[R];
-  const float* rj[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = wave + 4 * r;
-    const int gi = min(i0 + row, C - 1), gj = min(j0 + row, C - 1);
-    mi[r] = mb[gi]; mj[r] = mb[gj];
-    ri[r] = xb + (size_t)gi * n; rj[r] = xb + (size_t)gj * n;
+  // per-row constants of this wave's staging rows (wave w stages rows w, w+4, ...; lane = pixel of the chunk).
+  // Row addresses are rebuilt from 32-bit element offsets at every load (two integer ops against 64 MFMA cycles):
+  // 2 R row POINTERS took 128 registers and left one wave per SIMD.
+  // the rows' means wait in LDS (2 T floats): as registers they cost 2 R = 64 of the 256 a wave may have here
+  float* Mi = smem + 2 * T * LSF;
+  float* Mj = Mi + T;
+  if (tid < T) {
+    Mi[tid] = mb[min(i0 + tid, C - 1)];
+    Mj[tid] = mb[min(j0 + tid, C - 1)];
   }
-  float vi[R], vj[R];
-  auto load = [&](int ch) {                       // coalesced 256-B row segments, clamped (masked at the LDS store)
-    const int pc = min(ch * KN + lane, n - 1);
+  // Buffer loads: ONE per-lane offset (this wave's first row + the chunk's pixel) and the row in the scalar offset,
+  // so no per-row address registers exist (as hoisted loop invariants they cost 64-128 registers and spilled).
+  // Rows past C and pixels past n are out of the image's range or belong to the next row: never faulting, and
+  // masked at the LDS store.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, int(unsigned(size_t(C) * n * sizeof(float))), 0x00020000);
+  const unsigned row_bytes = unsigned(n) * 4u;
+  float vi[R], vj[DIAG ? 1 : R];
+  auto load = [&](int ch) {                       // coalesced 256-B row segments
+    const int vo = int(unsigned(wave) * row_bytes + unsigned(ch * KN + lane) * 4u);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      vi[r] = ri[r][pc];
-      if (!diag) vj[r] = rj[r][pc];
+      vi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, int(unsigned(i0 + 4 * r) * row_bytes), 0));
+      if (!DIAG)
+        vj[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, int(unsigned(j0 + 4 * r) * row_bytes), 0));
     }
   };
   if (c_begin < c_end) load(c_begin);
@@ -91,8 +89,8 @@ __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = wave + 4 * r;
-      Xi[row * LSF + lane] = (pok && i0 + row < C) ? vi[r] - mi[r] : 0.f;      // exactly the reference's x - mu
-      if (!diag) Xj[row * LSF + lane] = (pok && j0 + row < C) ? vj[r] - mj[r] : 0.f;
+      Xi[row * LSF + lane] = (pok && i0 + row < C) ? vi[r] - Mi[row] : 0.f;    // exactly the reference's x - mu
+      if (!DIAG) Xj[row * LSF + lane] = (pok && j0 + row < C) ? vj[r] - Mj[row] : 0.f;
     }
     __syncthreads();
     if (ch + 1 < c_end) load(ch + 1);              // next chunk's global loads fly under this chunk's MFMAs
@@ -111,7 +109,6 @@ __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x
           acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[q], acc[m][q], 0, 0, 0);
     }
   }
-  float* slab = slabs + ((size_t)split * B + b) * C * C;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -123,6 +120,25 @@ __global__ __launch_bounds__(NT) void cov_fwd_kernel(const float* __restrict__ x
         if (i < C && j < C) slab[(size_t)i * C + j] = acc[m][q][k];
       }
     }
+}
+
+template <int T>
+__global__ __launch_bounds__(NT, 2) void cov_fwd_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ mean,
+                                                       float* __restrict__ slabs, int B, int C, int n,
+                                                       int chunks_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tiles = (C + T - 1) / T;
+  int ti, tj;
+  tri_tile(blockIdx.x, tiles, ti, tj);
+  const int split = blockIdx.y, b = blockIdx.z;
+  const float* xb = x + (size_t)b * C * n;
+  const float* mb = mean + (size_t)b * C;
+  const int nchunks = (n + KN - 1) / KN;
+  const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, nchunks);
+  float* slab = slabs + ((size_t)split * B + b) * C * C;
+  if (ti == tj) cov_tile<T, true>(xb, mb, slab, smem, C, n, ti * T, tj * T, c_begin, c_end);
+  else cov_tile<T, false>(xb, mb, slab, smem, C, n, ti * T, tj * T, c_begin, c_end);
 }
 
 // Fixed-order sum of the split-K slabs; element (i, j) of a strictly-lower TILE is read from (j, i) of the upper
@@ -268,14 +284,15 @@ extern "C" int st_cov_fwd(const float* x, const float* mean, float* cov, float* 
                           int n, st_stream_t stream) {
   ST_REQUIRE(x && mean && cov && workspace, "st_cov_fwd: null pointer");
   ST_REQUIRE(b > 0 && c > 0 && n > 0, "st_cov_fwd: bad dims b=%d c=%d n=%d", b, c, n);
+  ST_REQUIRE((long long)(c + 128) * n * 4 < (1LL << 31), "st_cov_fwd: one image of %d x %d floats exceeds the 2 GB a buffer offset spans", c, n);
   const Plan p = plan_for(b, c, n);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.tiles * (p.tiles + 1) / 2, p.nsplit, b);
   if (p.T == 64) {
-    hipLaunchKernelGGL(cov_fwd_kernel<64>, grid, dim3(NT), 2 * 64 * LSF * sizeof(float), s, x, mean,
+    hipLaunchKernelGGL(cov_fwd_kernel<64>, grid, dim3(NT), (2 * 64 * LSF + 2 * 64) * sizeof(float), s, x, mean,
                        workspace, b, c, n, p.chunks_per_split);
   } else {
-    constexpr int lds = 2 * 128 * LSF * sizeof(float);
+    constexpr int lds = (2 * 128 * LSF + 2 * 128) * sizeof(float);
     ST_LAUNCH_DYN_LDS("st_cov_fwd", cov_fwd_kernel<128>, grid, dim3(NT), lds, s, x, mean, workspace, b, c, n,
                       p.chunks_per_split);
   }
