@@ -5,6 +5,7 @@ training step needs (targets are features of the un-trained content/style images
 trainer.py:446-457)."""
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -442,6 +443,7 @@ class VincentStyleLoss(nn.Module):
 
     # ---- the step engine's form: layers grouped by channel count, groups on side streams ---------------
     def _side_stream(self, key):
+        """Side stream number ``key`` (0 .. LANES-1) of the current device."""
         dev = torch.cuda.current_device()
         st = self._streams.get((dev, key))
         if st is None:
@@ -455,14 +457,23 @@ class VincentStyleLoss(nn.Module):
             groups.setdefault(int(f.shape[1]), []).append(i)
         return sorted(groups.items(), key=lambda kv: -kv[0])          # widest (slowest) group first
 
+    #: Side streams ("lanes") for the per-group eigen / Newton-Schulz jobs.  The GPU has FOUR hardware queues per
+    #: process (GPU_MAX_HW_QUEUES): streams beyond that share a queue and run back to back in submission order.
+    #: Round 2 first used one stream per (side, channel count) = 8 side streams: 54.7 ms per Gram step.  With three
+    #: lanes in all -- the widest group (the two 512-channel taps, stacked into one 13 ms call) alone on lane 0, the
+    #: next group on lane 1, every narrower group back to back on lane 2 -- the step takes 50.2 ms.  Splitting the
+    #: widest group's two layers over two lanes instead of stacking them: 70.5 ms (two rocSOLVER chains of ~2000
+    #: dependent launches each slow each other down far more than stacking costs).
+    LANES = int(os.environ.get("ST_VINCENT_LANES", "3"))
+
     @torch.no_grad()
     def prepare_targets(self, target_feats):
         """Style-image side of every layer; returns an opaque list for ``forward_multi``.  Work is issued on side
-        streams and NOT waited for here."""
+        streams and NOT waited for here (one stacked call per group; lanes as in forward_multi)."""
         cur = torch.cuda.current_stream()
         prepared = []
-        for c, idxs in self._groups(target_feats):
-            st = self._side_stream(("stl", c))
+        for g, (c, idxs) in enumerate(self._groups(target_feats)):
+            st = self._side_stream(min(g, self.LANES - 1))
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 moments = [self.calc_2_moments(target_feats[i]) for i in idxs]
@@ -479,19 +490,21 @@ class VincentStyleLoss(nn.Module):
         """Sum over the layers of ``forward(input_feats[i], target_i)`` given ``prepare_targets(targets)``."""
         cur = torch.cuda.current_stream()
         moments = [self.calc_2_moments(f) for f in input_feats]          # MFMA covariances, main stream
-        parts = []
-        for c, idxs, mean_stl, root, tr, st_stl in prepared:
-            st = self._side_stream(("syn", c))
-            st.wait_stream(cur)
+        nb = int(input_feats[0].shape[0])
+        parts, used = [], []
+        for g, (c, idxs, mean_stl, root, tr, st_stl) in enumerate(prepared):      # widest group first
+            lane = min(g, self.LANES - 1)
+            st = self._side_stream(lane)
+            if st not in used:
+                st.wait_stream(cur)
+                used.append(st)
             st.wait_stream(st_stl)
-            nb = int(input_feats[idxs[0]].shape[0])
             with torch.cuda.stream(st):
                 cov_synth = torch.cat([moments[i][1] for i in idxs]) if len(idxs) > 1 else moments[idxs[0]][1]
-                # the mean term is per layer (a scalar over the layer's whole batch, losses.py:75)
-                mds = [((moments[i][0] - m) ** 2).mean() for i, m in zip(idxs, mean_stl)]
                 rest = self._synth_side(root, tr, cov_synth)
-                for k in range(len(idxs)):
-                    dist = mds[k] + rest[k * nb:(k + 1) * nb]
+                for k, i in enumerate(idxs):
+                    # the mean term is per layer (a scalar over the layer's whole batch, losses.py:75)
+                    dist = ((moments[i][0] - mean_stl[k]) ** 2).mean() + rest[k * nb:(k + 1) * nb]
                     parts.append((dist.mean() * self.scale_factor, st))
             for t in (root, tr, *mean_stl, *(moments[i][k] for i in idxs for k in (0, 1))):
                 t.record_stream(st)
