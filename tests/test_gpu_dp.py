@@ -60,9 +60,14 @@ def _trajectory(run, bucket, decoder, transformer, batches, lo, hi):
     return [g.cpu() for g in grads], losses, weights.cpu()
 
 
-def _worker(rank, world, port, q):
+RUNS = (("frozen", False, TINY_LR), ("eager", False, 1e-4), ("graph", True, 1e-4))
+
+
+def _worker(rank, world, port, q, compute="f32", runs=RUNS):
     sys.path.insert(0, REPO)
+    from style_transfer_amd import precision
     from style_transfer_amd.parallel import init_process_group
+    precision.set_compute_dtype(compute)
     dist, _ = init_process_group(rehearsal=True, local_rank=rank, init_method=f"tcp://127.0.0.1:{port}",
                                  rank=rank, world_size=world)
     batches = _batches()
@@ -70,7 +75,7 @@ def _worker(rank, world, port, q):
     result = {}
     # "frozen": lr = 0, the weights stay put, so EVERY step compares gradients of identical
     # weights on a new batch; the other two runs take real Adam steps (lr 1e-4), eager and graph-replayed
-    for name, use_graph, lr_value in (("frozen", False, TINY_LR), ("eager", False, 1e-4), ("graph", True, 1e-4)):
+    for name, use_graph, lr_value in runs:
         tr, run, bucket, decoder, transformer = _make(use_graph=use_graph, lr_value=lr_value)
         assert tr.world_size == world and tr.graph_capable()
         grads, losses, weights = _trajectory(run, bucket, decoder, transformer, batches, lo, lo + PER_RANK)
@@ -93,11 +98,10 @@ def _rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def test_two_rank_step_equals_large_batch_step():
+def _two_ranks(port, compute="f32", runs=RUNS):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q, compute, runs)) for r in range(WORLD)]
     for p in procs:
         p.start()
     try:
@@ -106,6 +110,11 @@ def test_two_rank_step_equals_large_batch_step():
         for p in procs:
             p.join(timeout=120)
     assert all(p.exitcode == 0 for p in procs)
+    return both
+
+
+def test_two_rank_step_equals_large_batch_step():
+    both = _two_ranks(29600 + os.getpid() % 2000)
     got = both["frozen"]
 
     # (1) 2 ranks x 2 images == single process, whole batch, same HIP path (world_size 1: no collectives).  Weights
@@ -139,6 +148,33 @@ def test_two_rank_step_equals_large_batch_step():
             assert torch.allclose(a, b, rtol=1e-5, atol=0), (step, r, a, b)
         assert _rel_l2(gr["grads"][step], got["grads"][step]) < 1e-5, step
     assert _rel_l2(gr["weights"], got["weights"]) < 1e-5
+
+
+def test_two_rank_step_equals_large_batch_step_in_bf16_compute_mode():
+    """BASELINE configs[3] is data parallel in the bf16 compute mode: the same exactness statement there.  Every
+    image's convolutions round identically whatever the batch they run in (bf16 operands, fp32 accumulation per
+    output element), so the 2-rank step differs from the 4-image step only in fp32 summation order, as in fp32."""
+    from style_transfer_amd import precision
+    got = _two_ranks(29650 + os.getpid() % 2000, "bf16", (("frozen", False, TINY_LR),))["frozen"]
+    precision.set_compute_dtype("bf16")
+    try:
+        tr, run, bucket, decoder, transformer = _make(world_size_override=1, use_graph=False, lr_value=TINY_LR)
+        grads, losses, weights = _trajectory(run, bucket, decoder, transformer, _batches(), 0, PER_RANK * WORLD)
+    finally:
+        precision.set_compute_dtype("f32")
+    for step in range(STEPS):
+        ref_l = losses[step].double()
+        dp = torch.stack([torch.as_tensor(l[step]).double() for l in got["losses"]])
+        for i, name in enumerate(("content", "style", "variation")):
+            assert float(dp[:, i].mean()) == pytest.approx(float(ref_l[i]), rel=1e-4), (step, name)
+        for r in range(WORLD):
+            assert float(dp[r, 3]) == pytest.approx(float(ref_l[3]), rel=1e-4), (step, "hist", r)
+        assert _rel_l2(got["grads"][step], grads[step]) < 1e-3, (step, _rel_l2(got["grads"][step], grads[step]))
+    assert _rel_l2(got["weights"], weights) < 1e-6
+    # ... and it WAS the bf16 mode: the fp32 step's gradient is a visibly different number
+    tr, run, bucket, decoder, transformer = _make(world_size_override=1, use_graph=False, lr_value=TINY_LR)
+    g32, _, _ = _trajectory(run, bucket, decoder, transformer, _batches()[:1], 0, PER_RANK * WORLD)
+    assert _rel_l2(grads[0], g32[0]) > 1e-3
 
 
 # ---- the real RCCL backend, one rank ---------------------------------------------------------------------------
