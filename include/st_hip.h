@@ -167,8 +167,12 @@ int st_conv3x3_dgrad_bf16x3(const float* dy, const float* y_gate, const void* w_
                             float* workspace, const float* dx_gate, int n, int cout, int h, int w, int cin,
                             int upsample2x, int pad_mode, st_stream_t stream);
 
-/* bf16-operand weight / bias gradient; same arguments, outputs (fp32 dw / dbias) and workspace
- * (st_conv3x3_wgrad_workspace_bytes) as st_conv3x3_wgrad. */
+/* bf16-operand weight / bias gradient (decoder training in the bf16 compute mode, generator.py:85-130 trained by
+ * trainer.py:286-291, 471-473); same arguments and outputs (fp32 dw / dbias) as st_conv3x3_wgrad.  Its workspace is
+ * st_conv3x3_wgrad_bf16_workspace_bytes(n, cout, cin, h_out, w_out) bytes (h_out / w_out: the OUTPUT size, i.e. twice
+ * hin / win with upsample2x): the split-K slabs plus, for layers made of whole 4 x 32 pixel tiles, the two operands
+ * in the form the GEMM consumes -- bf16(dy * gate) and the padded (upsampled) bf16 input -- written once per call. */
+size_t st_conv3x3_wgrad_bf16_workspace_bytes(int n, int cout, int cin, int h, int w);
 int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const float* y_gate, float* dw,
                           float* dbias, float* workspace, int n, int cin, int hin, int win, int cout,
                           int upsample2x, int pad_mode, st_stream_t stream);

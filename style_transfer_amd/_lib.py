@@ -48,6 +48,7 @@ SIGNATURES = {
     "st_conv3x3_dgrad_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+"st_conv3x3_wgrad_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -57,6 +57,10 @@ struct WgradParams {
   int up, pad_zero;
   int tiles_x, tiles_y, ntiles;   // pixel tiles per image / total
   int tiles_per_split, nsplit;
+  // staged bf16 path (conv3x3_wgrad_bf16s_kernel): operands prepared once per call by the wgrad_prep_* kernels
+  const unsigned short* g16;   // [n][cout][H][W] bf16, gate applied
+  const unsigned short* x16;   // [n][cin][H + 2][wp] bf16: pad (and x2 upsample) materialised, pixel gx at column gx + 8
+  int wp;                      // row pitch of x16 in elements (multiple of 8)
 };
 
 // BO_ output channels x CI_ input channels per block; BO_ / 32 channel tiles x (CI_ * 9 / 32) column tiles are
@@ -458,6 +462,239 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16_kernel(WgradParam
   }
 }
 
+// ---- staged form: both operands prepared ONCE per call ------------------------------------------------------
+// Measured on the decoder layers at B = 8 (tools/bench_conv_layers.py --mode wgrad --compute bf16): the kernel above
+// takes 0.52 ms for 256 -> 256 at 128 x 128 with or WITHOUT its MFMA loop, 0.18 ms without its global loads, 0.13 ms
+// without any staging: it is bound by operand traffic.  Every block re-reads the fp32 dy tile and its fp32 gate for
+// each of the cin / 32 channel chunks (and x for each of the cout / 128): 2.5 GB per call for 154 GFLOP.  Here two
+// elementwise passes write what the GEMM actually consumes --
+//   G  = bf16(dy * (ygate > 0))                [n][cout][H][W]           (+ the bias gradient: row sums, in fp32)
+//   Xp = bf16(pad1(upsample?(x)))              [n][cin][H + 2][W + 16]   pixel gx at column gx + 8
+// -- and the GEMM stages plain 16-B vectors: no gate, no clamps, no conversion, a quarter of the bytes for dy and
+// half for x (0.67 GB per call for that layer).  The three horizontally shifted copies of an x row segment come
+// from one aligned 16-B load + its two neighbour dwords by v_alignbit.  Needs W % 32 == 0 and H % 4 == 0 (whole
+// tiles; every decoder layer), otherwise the kernel above runs.
+constexpr int XPAD = 8;             // left / right padding columns of an Xp row (keeps 16-B alignment)
+
+template <bool GATE>
+__global__ __launch_bounds__(256) void wgrad_prep_g_kernel(const float* __restrict__ dy,
+                                                          const float* __restrict__ ygate,
+                                                          unsigned short* __restrict__ g16,
+                                                          float* __restrict__ bias_part, int hw) {
+  __shared__ float red[4];
+  const size_t base = size_t(blockIdx.x) * hw;          // one (image, channel) plane per block; hw % 8 == 0
+  float sum = 0.f;
+  for (int i = threadIdx.x * 8; i < hw; i += 256 * 8) {
+    f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dy + base + i));
+    f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dy + base + i + 4));
+    if (GATE) {
+      const f32x4 ya = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ygate + base + i));
+      const f32x4 yb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ygate + base + i + 4));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k] = ya[k] > 0.f ? a[k] : 0.f;
+        b[k] = yb[k] > 0.f ? b[k] : 0.f;
+      }
+    }
+    bf16x8 pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pk[k] = (__bf16)a[k];
+      pk[4 + k] = (__bf16)b[k];
+      sum += a[k] + b[k];
+    }
+    *reinterpret_cast<u32x4*>(g16 + base + i) = __builtin_bit_cast(u32x4, pk);
+  }
+  sum = st::block_sum<256>(sum, red);
+  if (bias_part && threadIdx.x == 0) bias_part[blockIdx.x] = sum;     // [image][channel]: a slab per image
+}
+
+// One item = 8 consecutive columns (16 B) of one padded row; interior items read two aligned float4 (one, doubled,
+// under the x2 upsample), the two edge items of a row hold one halo pixel each.
+__global__ __launch_bounds__(256) void wgrad_prep_x_kernel(const float* __restrict__ x,
+                                                          unsigned short* __restrict__ x16, long long planes,
+                                                          int hs, int ws, int H, int W, int wp, int up,
+                                                          int pad_zero) {
+  const int groups = wp / 8;
+  const long long per_plane = (long long)(H + 2) * groups, total = planes * per_plane;
+  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += gridDim.x * 256LL) {
+    const long long plane = idx / per_plane;
+    const int rem = int(idx - plane * per_plane);
+    const int py = rem / groups, g = rem - py * groups;
+    const float* xp = x + plane * size_t(hs) * ws;
+    const int gy = py - 1;
+    const bool rowin = gy >= 0 && gy < H;
+    int cy = min(max(gy, 0), H - 1);
+    if (up) cy >>= 1;
+    const float* row = xp + size_t(cy) * ws;
+    const bool keep = rowin || !pad_zero;
+    bf16x8 pk;
+    if (g >= 1 && g < groups - 1) {
+      const int gx0 = (g - 1) * 8;                                  // 0 .. W - 8, a multiple of 8
+      float v[8];
+      if (up) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row + (gx0 >> 1));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a[k >> 1];
+      } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row + gx0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(row + gx0 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pk[k] = (__bf16)(keep ? v[k] : 0.f);
+    } else {
+      // g == 0: column 7 is pixel -1; g == groups - 1: column 0 is pixel W (replicated edge, or zero)
+      const float e = (keep && !pad_zero) ? row[g == 0 ? 0 : ((W - 1) >> up)] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pk[k] = (__bf16)0.f;
+      if (g == 0) pk[7] = (__bf16)e; else pk[0] = (__bf16)e;
+    }
+    *reinterpret_cast<u32x4*>(x16 + plane * size_t(H + 2) * wp + size_t(py) * wp + g * 8) = __builtin_bit_cast(u32x4, pk);
+  }
+}
+
+// Block shape <BO_, CI_>: 12 waves = (BO_ / 32 channel tiles) x (CI_ * 9 / 32 / 3 groups of three column tiles):
+// <128, 32> for cout > 64, <64, 64> for cout <= 64 (no MFMA rows spent on padding; the decoder's 128 -> 64 and
+// 64 -> 64 layers).  The copy stride of the wider X image keeps the residue (mod 256 B) that makes every
+// ds_read_b128 group conflict-free (the channel stride repeats its residues every 16 channels).
+template <int BO_, int CI_>
+struct SShape {
+  static constexpr int OT = BO_ / 32, GROUPS = 12 / OT;
+  static_assert(OT * GROUPS == 12 && CI_ * 9 / 32 == GROUPS * WJT && (CI_ * 9) % 32 == 0, "12 waves x 3 column tiles");
+  static constexpr int G_BYTES_ = BO_ * G_ROW_B;
+  static constexpr int XCOPY = CI_ == 32 ? X_COPY_B : 31856;
+  static_assert(XCOPY >= CI_ * X_CH_B && XCOPY % 256 == X_COPY_B % 256, "X copy stride");
+  static constexpr int NG = BO_ * TRB * 4, NGS_ = (NG + NTHREADS - 1) / NTHREADS;        // 16-B items of a G tile
+  static constexpr int NX = CI_ * HRB * 4, NXS_ = (NX + NTHREADS - 1) / NTHREADS;        // ... of the X halo
+  static constexpr size_t LDS = size_t(G_BYTES_) + 3 * size_t(XCOPY);
+};
+
+template <int BO_, int CI_>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradParams p) {
+  typedef SShape<BO_, CI_> S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
+  unsigned char* Gs = smemb;
+  unsigned char* Xs = smemb + S::G_BYTES_;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int c0 = blockIdx.x * CI_;
+  const int o0 = blockIdx.y * BO_;
+  const int split = blockIdx.z;
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
+  const size_t xplane = size_t(p.H + 2) * p.wp;
+  const size_t gplane = size_t(p.H) * p.W;
+
+  f32x16 acc[WJT];
+#pragma unroll
+  for (int t = 0; t < WJT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int ot = wave % S::OT, jt0 = (wave / S::OT) * WJT;
+  const unsigned char* aPtr = Gs + (ot * 32 + li) * G_ROW_B + lh * 16;
+  int bOff[WJT];
+#pragma unroll
+  for (int jt = 0; jt < WJT; ++jt) {
+    const int j = (jt0 + jt) * 32 + li;
+    const int c = j / 9, tap = j - c * 9;
+    bOff[jt] = (tap % 3) * S::XCOPY + c * X_CH_B + (tap / 3) * X_ROW_B + lh * 16;
+  }
+
+  u32x4 gv[S::NGS_], xv[S::NXS_];
+  unsigned xl[S::NXS_], xr2[S::NXS_];
+  auto load = [&](int t) {
+    int rem = t;
+    const int tx = rem % p.tiles_x;
+    rem /= p.tiles_x;
+    const int ty = rem % p.tiles_y;
+    const int b = rem / p.tiles_y;
+    const int x0 = tx * TW, y0 = ty * TRB;
+#pragma unroll
+    for (int i = 0; i < S::NGS_; ++i) {
+      const int g = min(tid + i * NTHREADS, S::NG - 1);
+      const int seg = g >> 2, q = g & 3;                         // seg = channel * 4 + tile row
+      const int o = min(o0 + (seg >> 2), p.cout - 1);
+      gv[i] = *reinterpret_cast<const u32x4*>(p.g16 + (size_t(b) * p.cout + o) * gplane +
+                                              size_t(y0 + (seg & 3)) * p.W + x0 + q * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < S::NXS_; ++i) {
+      const int it = min(tid + i * NTHREADS, S::NX - 1);         // channel xc, halo row xr, 8-pixel group xq
+      const int xq = it & 3, xr = (it >> 2) % HRB, xc = it / (4 * HRB);
+      const unsigned short* row = p.x16 + (size_t(b) * p.cin + min(c0 + xc, p.cin - 1)) * xplane +
+                                  size_t(y0 + xr) * p.wp + XPAD + x0 + xq * 8;
+      xv[i] = *reinterpret_cast<const u32x4*>(row);
+      xl[i] = *reinterpret_cast<const unsigned*>(row - 2);
+      xr2[i] = *reinterpret_cast<const unsigned*>(row + 8);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < S::NGS_; ++i) {
+      const int g = tid + i * NTHREADS;
+      if (g >= S::NG) break;
+      const int seg = g >> 2, q = g & 3;
+      u32x4 v = gv[i];
+      if (o0 + (seg >> 2) >= p.cout) v = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(Gs + (seg >> 2) * G_ROW_B + ((seg & 3) * TW + q * 8) * 2) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < S::NXS_; ++i) {
+      const int it = tid + i * NTHREADS;
+      if (it >= S::NX) break;
+      const int xq = it & 3, xr = (it >> 2) % HRB, xc = it / (4 * HRB);
+      u32x4 mid = xv[i];
+      unsigned l = xl[i], r = xr2[i];
+      if (c0 + xc >= p.cin) { mid = u32x4{0u, 0u, 0u, 0u}; l = 0u; r = 0u; }
+      // dword k of `mid` holds pixels 2k (low half) and 2k + 1; one pixel to the left / right by v_alignbit
+      const unsigned s01 = __builtin_amdgcn_alignbit(mid[1], mid[0], 16);
+      const unsigned s12 = __builtin_amdgcn_alignbit(mid[2], mid[1], 16);
+      const unsigned s23 = __builtin_amdgcn_alignbit(mid[3], mid[2], 16);
+      const u32x4 left = {__builtin_amdgcn_alignbit(mid[0], l, 16), s01, s12, s23};
+      const u32x4 right = {s01, s12, s23, __builtin_amdgcn_alignbit(r, mid[3], 16)};
+      unsigned char* dst = Xs + xc * X_CH_B + xr * X_ROW_B + xq * 16;
+      *reinterpret_cast<u32x4*>(dst) = left;                       // kx = 0: pixels x - 1 ..
+      *reinterpret_cast<u32x4*>(dst + S::XCOPY) = mid;             // kx = 1
+      *reinterpret_cast<u32x4*>(dst + 2 * S::XCOPY) = right;       // kx = 2: pixels x + 1 ..
+    }
+  };
+
+  if (t_begin < t_end) load(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();   // previous tile's MFMA phase is done with LDS
+    store();
+    __syncthreads();
+    if (t + 1 < t_end) load(t + 1);   // in flight during the MFMA phase
+#pragma unroll
+    for (int s = 0; s < TPB / 16; ++s) {
+      const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(aPtr + s * 32));
+      const int poff = (s >> 1) * X_ROW_B + (s & 1) * 32;
+#pragma unroll
+      for (int jt = 0; jt < WJT; ++jt) {
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Xs + bOff[jt] + poff));
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[jt], 0, 0, 0);
+      }
+    }
+  }
+
+  float* slab = p.slabs + size_t(split) * p.cout * p.cin * 9;
+#pragma unroll
+  for (int jt = 0; jt < WJT; ++jt) {
+    const int jg = c0 * 9 + (jt0 + jt) * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (o < p.cout && jg < p.cin * 9)
+        slab[size_t(o) * p.cin * 9 + jg] = acc[jt][r];
+    }
+  }
+}
+
 }  // namespace bf
 
 struct Plan {
@@ -524,6 +761,7 @@ extern "C" size_t st_conv3x3_wgrad_workspace_bytes(int n, int cout, int cin, int
   wgrad_shape(cout, &bo, &ci);
   const int nsplit = std::max({make_plan(n, cout, cin, h, w, TR, bo, ci).nsplit,
                                make_plan(n, cout, cin, h, w, bf::TRB).nsplit,
+                               make_plan(n, cout, cin, h, w, bf::TRB, bo, ci).nsplit,
                                st::wgrad_small_nsplit(n, cout, cin, h, w)});
   return size_t(nsplit) * (size_t(cout) * cin * 9 + cout) * sizeof(float);
 }
@@ -583,6 +821,21 @@ extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_
   return st::check_launch("st_conv3x3_wgrad(reduce)");
 }
 
+// staged bf16 path: whole 4 x 32 pixel tiles, 16-B rows
+static bool wgrad_bf16_staged_ok(int cout, int H, int W) {
+  return cout != 3 && W % 32 == 0 && H % bf::TRB == 0;
+}
+static size_t align16(size_t bytes) { return (bytes + 15) & ~size_t(15); }
+
+extern "C" size_t st_conv3x3_wgrad_bf16_workspace_bytes(int n, int cout, int cin, int h, int w) {
+  size_t bytes = align16(st_conv3x3_wgrad_workspace_bytes(n, cout, cin, h, w));
+  if (bytes == 0 || !wgrad_bf16_staged_ok(cout, h, w)) return bytes;
+  bytes += align16(size_t(n) * cout * sizeof(float));                                   // bias rows per image
+  bytes += align16(size_t(n) * cout * h * w * sizeof(unsigned short));                   // G
+  bytes += align16(size_t(n) * cin * (h + 2) * (w + 2 * bf::XPAD) * sizeof(unsigned short));   // Xp
+  return bytes;
+}
+
 extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const float* y_gate, float* dw,
                                      float* dbias, float* workspace, int n, int cin, int hin, int win,
                                      int cout, int upsample2x, int pad_mode, st_stream_t stream) {
@@ -604,7 +857,12 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
   }
   ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, bf::TRB) <= 0x7fffffffLL,
              "st_conv3x3_wgrad_bf16: too many pixel tiles");
-  const Plan pl = make_plan(n, cout, cin, H, W, bf::TRB);
+  const bool staged = wgrad_bf16_staged_ok(cout, H, W) && (long long)n * cout <= 0x7fffffffLL &&
+                      (long long)n * cin <= 0x7fffffffLL && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(workspace) % 16 == 0;
+  int sbo = BO, sci = CI;
+  if (staged) wgrad_shape(cout, &sbo, &sci);          // <64, 64> for cout <= 64, as in the fp32 kernel
+  const Plan pl = make_plan(n, cout, cin, H, W, bf::TRB, sbo, sci);
   WgradParams p;
   p.dy = dy; p.ygate = y_gate; p.x = x;
   p.slabs = workspace;
@@ -613,8 +871,48 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
   p.up = up; p.pad_zero = pad_mode == ST_PAD_ZERO;
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
   p.tiles_per_split = pl.tiles_per_split; p.nsplit = pl.nsplit;
+  p.g16 = nullptr; p.x16 = nullptr; p.wp = 0;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(st::cdiv(cin, CI), st::cdiv(cout, BO), pl.nsplit);
+  dim3 grid(st::cdiv(cin, sci), st::cdiv(cout, sbo), pl.nsplit);
+  if (staged) {
+    // operands prepared once (see the staged kernels): workspace = [slabs | bias rows per image | G | Xp]
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    size_t off = align16(st_conv3x3_wgrad_workspace_bytes(n, cout, cin, H, W));
+    float* bias_part = reinterpret_cast<float*>(wsb + off);
+    off += align16(size_t(n) * cout * sizeof(float));
+    unsigned short* g16 = reinterpret_cast<unsigned short*>(wsb + off);
+    off += align16(size_t(n) * cout * H * W * sizeof(unsigned short));
+    unsigned short* x16 = reinterpret_cast<unsigned short*>(wsb + off);
+    const int wp = W + 2 * bf::XPAD;
+    if (y_gate)
+      hipLaunchKernelGGL(bf::wgrad_prep_g_kernel<true>, dim3((unsigned)(n * cout)), dim3(256), 0, s, dy, y_gate, g16,
+                         dbias ? bias_part : nullptr, H * W);
+    else
+      hipLaunchKernelGGL(bf::wgrad_prep_g_kernel<false>, dim3((unsigned)(n * cout)), dim3(256), 0, s, dy, y_gate, g16,
+                         dbias ? bias_part : nullptr, H * W);
+    {
+      const long long items = (long long)n * cin * (H + 2) * (wp / 8);
+      hipLaunchKernelGGL(bf::wgrad_prep_x_kernel, dim3((unsigned)std::min<long long>(st::cdivll(items, 256), 16384)),
+                         dim3(256), 0, s, x, x16, (long long)n * cin, hin, win, H, W, wp, up, p.pad_zero);
+    }
+    p.g16 = g16; p.x16 = x16; p.wp = wp;
+    p.bias_slabs = nullptr;
+    if (sbo == 64)
+      ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), grid, dim3(NTHREADS),
+                        (bf::SShape<64, 64>::LDS), s, p);
+    else
+      ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", (bf::conv3x3_wgrad_bf16s_kernel<128, 32>), grid, dim3(NTHREADS),
+                        (bf::SShape<128, 32>::LDS), s, p);
+    int rc = st::check_launch("st_conv3x3_wgrad_bf16(staged)");
+    if (rc != ST_OK) return rc;
+    const long long nw = (long long)cout * cin * 9;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(nw, 256), 2048)),
+                       dim3(256), 0, s, p.slabs, dw, nw, pl.nsplit);
+    if (dbias)      // the per-image row sums are "slabs" of [cout]: same fixed-order reduction
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(st::cdiv(cout, 256)), dim3(256), 0, s, bias_part, dbias,
+                         (long long)cout, n);
+    return st::check_launch("st_conv3x3_wgrad_bf16(staged, reduce)");
+  }
   if (y_gate)   // 82.8 KB of dynamic LDS (> the 64 KB default limit)
     ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", bf::conv3x3_wgrad_bf16_kernel<true>, grid, dim3(NTHREADS),
                       bf::LDS_BYTES_B, s, p);

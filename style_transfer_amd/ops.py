@@ -300,8 +300,8 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tens
         db = db_out
     else:
         db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    nbytes = lib.st_conv3x3_wgrad_workspace_bytes(n, cout, cin, h * s, w * s)
-    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.st_conv3x3_wgrad_bf16_workspace_bytes if compute == "bf16" else lib.st_conv3x3_wgrad_workspace_bytes
+    ws = torch.empty(ws_bytes(n, cout, cin, h * s, w * s) // 4, dtype=torch.float32, device=x.device)
     ev = None
     if KERNEL_TIMER.enabled:
         ev = KERNEL_TIMER.record("conv3x3_wgrad_bf16_kernel" if compute == "bf16" else "conv3x3_wgrad_kernel",

@@ -100,6 +100,14 @@ def test_conv3x3_bf16_dgrad(ops, n, cin, cout, h, w, up, pad, relu):
 @pytest.mark.parametrize("n,cin,cout,h,w,up,pad,relu", [c for c in CASES if not (c[5] and c[6] == "zero")] + [
     (2, 40, 70, 37, 50, False, "replicate", True),     # ragged tiles in every dimension
     (1, 64, 64, 130, 66, False, "zero", True),         # many 4-row pixel tiles -> several split-K slabs
+    # whole 4 x 32 pixel tiles: the staged form (operands written once as bf16: gated dy, padded / upsampled x)
+    (2, 40, 70, 36, 64, False, "replicate", True),     # ragged channel blocks in both operands
+    (1, 64, 256, 32, 96, False, "zero", True),         # zero pad, two output-channel blocks, three column tiles
+    (2, 32, 64, 16, 32, True, "replicate", True),      # fused x2 upsample (source 16 x 32 -> 32 x 64)
+    (1, 24, 48, 64, 32, False, "replicate", False),    # no gate
+    (1, 8, 16, 8, 16, True, "replicate", False),       # upsampled to one tile row of 16 x 32, no gate
+    (1, 128, 64, 32, 64, False, "replicate", True),    # cout <= 64: the <64, 64> block shape, two channel blocks
+    (2, 72, 40, 20, 32, True, "replicate", True),      # ... ragged in both channel dimensions, upsampled
 ])
 def test_conv3x3_bf16_wgrad(ops, n, cin, cout, h, w, up, pad, relu):
     g = torch.Generator().manual_seed(13 + n * 1000 + cin + cout + h)
