@@ -443,12 +443,10 @@ class VincentStyleLoss(nn.Module):
 
     # ---- the step engine's form: layers grouped by channel count, groups on side streams ---------------
     def _side_stream(self, key):
-        """Side stream number ``key`` (0 .. LANES-1) of the current device."""
-        dev = torch.cuda.current_device()
-        st = self._streams.get((dev, key))
-        if st is None:
-            st = self._streams[(dev, key)] = torch.cuda.Stream()
-        return st
+        """Side stream number ``key`` (0 .. LANES-1) of the current device: streams that were MEASURED to overlap with
+        the current stream and with each other (streams.concurrent_lanes), not merely distinct stream objects."""
+        from .streams import concurrent_lanes
+        return concurrent_lanes(self.LANES)[key]
 
     @staticmethod
     def _groups(feats):
@@ -461,9 +459,11 @@ class VincentStyleLoss(nn.Module):
     #: process (GPU_MAX_HW_QUEUES): streams beyond that share a queue and run back to back in submission order.
     #: Round 2 first used one stream per (side, channel count) = 8 side streams: 54.7 ms per Gram step.  With three
     #: lanes in all -- the widest group (the two 512-channel taps, stacked into one 13 ms call) alone on lane 0, the
-    #: next group on lane 1, every narrower group back to back on lane 2 -- the step takes 50.2 ms.  Splitting the
-    #: widest group's two layers over two lanes instead of stacking them: 70.5 ms (two rocSOLVER chains of ~2000
-    #: dependent launches each slow each other down far more than stacking costs).
+    #: next group on lane 1, every narrower group back to back on lane 2 -- the step takes 47.0 ms, provided the lanes
+    #: sit on distinct hardware queues (streams.py picks them by measurement; 52-54 ms when two of them or a lane
+    #: and the main stream share a queue).  Splitting the widest group's two layers over two lanes instead of
+    #: stacking them: 70.5 ms (two rocSOLVER chains of ~2000 dependent launches each slow each other down far more
+    #: than stacking costs).
     LANES = int(os.environ.get("ST_VINCENT_LANES", "3"))
 
     @torch.no_grad()

@@ -74,3 +74,31 @@ def test_small_eigh_timing_report():
             print(f"\n[8,{c},{c}] {name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms", end="")
         print(f"   sweeps {eigh._small_pending[-1].tolist()}")
     eigh.check()
+
+
+def test_concurrent_lanes_are_distinct_cached_and_overlap():
+    """streams.concurrent_lanes: the Gram loss's side streams are chosen by measuring that they overlap with the
+    caller's stream and with each other (hardware queues are dealt round-robin over ALL streams of the process)."""
+    import time
+    from style_transfer_amd import streams
+    for _ in range(3):                                   # unrelated streams created (and used) before: must not matter
+        with torch.cuda.stream(torch.cuda.Stream()):
+            torch.zeros(4, device="cuda").add_(1)
+    lanes = streams.concurrent_lanes(3)
+    assert len(lanes) == 3 and len({l.cuda_stream for l in lanes}) == 3
+    assert streams.concurrent_lanes(3) is lanes           # cached per (device, main stream, n)
+    main = torch.cuda.current_stream()
+    assert all(l.cuda_stream != main.cuda_stream for l in lanes)
+
+    def spin(streams_):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for st in streams_:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(2_000_000)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    spin([main])
+    one = min(spin([main]) for _ in range(3))
+    four = min(spin([main, *lanes]) for _ in range(3))
+    assert four < 2.5 * one, (one, four)                  # four spin kernels in well under four times one

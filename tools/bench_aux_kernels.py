@@ -28,9 +28,14 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3      # us
 
 
+NO_GRAPH = "--no-graph" in sys.argv      # counter passes: plain launches only
+
+
 def graphed(fn):
     """fn captured in a HIP graph: the replay time is the GPU time of its kernels without the host's launch and
     autograd overhead (what a training step replayed from graphs pays).  Falls back to fn if capture fails."""
+    if NO_GRAPH:
+        return fn
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

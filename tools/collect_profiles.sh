@@ -43,15 +43,21 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/aux
     python3 "$R/tools/bench_aux_kernels.py" > "$O/aux_kernels.txt" 2> "$O/aux.err"
 cp "$(find $S/aux -name '*kernel_stats.csv' | head -1)" "$O/aux_kernel_stats.csv"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $S/auxf -o p -- \
-    python3 "$R/tools/bench_aux_kernels.py" > /dev/null 2> "$O/aux_fetch.err"
+    python3 "$R/tools/bench_aux_kernels.py" --no-graph > /dev/null 2> "$O/aux_fetch.err"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $S/auxw -o p -- \
-    python3 "$R/tools/bench_aux_kernels.py" > /dev/null 2> "$O/aux_write.err"
+    python3 "$R/tools/bench_aux_kernels.py" --no-graph > /dev/null 2> "$O/aux_write.err"
 python3 "$R/tools/pmc_hbm_csv.py" $S/auxf $S/auxw > "$O/aux_pmc_hbm.csv"
 
 echo "[8] kernel stats, Gram-variant training step"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/gram -o p -- \
     python3 "$R/tools/gram_step.py" 12 > /dev/null 2> "$O/gram.err"
 cp "$(find $S/gram -name '*kernel_stats.csv' | head -1)" "$O/train_gram_kernel_stats.csv"
+echo "[9] small convs, AdaIN, augmentation, per-layer weight gradients: timing tables"
+timeout -k 10 120 python3 "$R/tools/bench_small_convs.py" > "$O/small_convs.txt" 2> "$O/small.err"
+timeout -k 10 120 python3 "$R/tools/bench_adain.py" > "$O/adain.txt" 2> "$O/adain.err"
+timeout -k 10 120 python3 "$R/tools/bench_augment.py" > "$O/augment.txt" 2> "$O/augment.err"
+timeout -k 10 120 python3 "$R/tools/bench_conv_layers.py" --batch 8 --mode wgrad --compute bf16 --iters 10 \
+    > "$O/wgrad_bf16_layers.txt" 2> "$O/wgrad.err"
 rm -rf $S
 rm -f "$O"/*.err
 echo done
