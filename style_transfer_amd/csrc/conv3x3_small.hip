@@ -23,6 +23,7 @@
 namespace {
 
 constexpr int KC = 8;
+constexpr size_t WS_LDS_MAX = size_t(512) * 9 * 4 * sizeof(float);   // LDS weight image of the cout <= 4 kernels at cin = 512
 
 // ---- cin == 3, cout <= 64 ---------------------------------------------------------------
 // Weights go through LDS ([27 steps][64 couts], 6.9 KB, staged once per block) and are read with
@@ -393,12 +394,22 @@ int launch_cout_strip(const float* x, const float* wp, const float* bias, float*
   const int tiles_x = st::cdiv(w, LPR * 4), tiles_y = st::cdiv(h, (256 / LPR) * SR);
   const dim3 grid((unsigned)(n * tiles_x * tiles_y));
   const size_t lds = size_t(cin) * 9 * 4 * sizeof(float);
-  if (pad_zero)
+  // cin <= 512 (host check): up to 72 KB of dynamic LDS, opted in for that maximum once per device
+  if (pad_zero) {
+    static st::DynLdsOptIn optin;
+    const int rc = st::allow_dynamic_lds(conv3x3_cout_strip_kernel<3, LPR, SR, true>, WS_LDS_MAX, optin,
+                                         "st_conv3x3_fwd(cout=3, strips)");
+    if (rc != ST_OK) return rc;
     hipLaunchKernelGGL((conv3x3_cout_strip_kernel<3, LPR, SR, true>), grid, dim3(256), lds, s, x, wp, bias, y, cin, h,
                        w, cout_pad, relu, tiles_x, tiles_y);
-  else
+  } else {
+    static st::DynLdsOptIn optin;
+    const int rc = st::allow_dynamic_lds(conv3x3_cout_strip_kernel<3, LPR, SR, false>, WS_LDS_MAX, optin,
+                                         "st_conv3x3_fwd(cout=3, strips)");
+    if (rc != ST_OK) return rc;
     hipLaunchKernelGGL((conv3x3_cout_strip_kernel<3, LPR, SR, false>), grid, dim3(256), lds, s, x, wp, bias, y, cin, h,
                        w, cout_pad, relu, tiles_x, tiles_y);
+  }
   return st::check_launch("st_conv3x3_fwd(cout=3, strips)");
 }
 
@@ -571,6 +582,9 @@ bool conv3x3_small_fwd(const float* x, const float* w_packed, const float* bias,
     const int tiles_x = cdiv(w, FTW), tiles_y = cdiv(h, FTH);
     const long long blocks = (long long)n * tiles_x * tiles_y;
     if (blocks > 0x7fffffffLL) return false;
+    static st::DynLdsOptIn optin;      // weights of up to 512 channels: 72 KB of dynamic LDS
+    *rc = st::allow_dynamic_lds(conv3x3_cout_small_kernel<3>, WS_LDS_MAX, optin, "st_conv3x3_fwd(cout=3)");
+    if (*rc != ST_OK) return true;
     hipLaunchKernelGGL(conv3x3_cout_small_kernel<3>, dim3((unsigned)blocks), dim3(256), size_t(cin) * 9 * 4 * sizeof(float),
                        s, x, w_packed, bias, y,
                        cin, h, w, cout_pad, pad_zero, relu, tiles_x, tiles_y);

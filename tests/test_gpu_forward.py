@@ -54,6 +54,8 @@ def ops():
     (8, 8, 3, 4001, 68, False, "replicate", False),
     (1, 8, 3, 1030, 2048, False, "zero", True),
     (3, 24, 3, 1021, 700, False, "replicate", False),
+    (1, 512, 3, 512, 512, False, "replicate", False),  # 72 KB weight image in LDS (dynamic-LDS opt-in), strips
+    (1, 512, 3, 9, 20, False, "zero", True),           # ... and the LDS-tiled kernel
 ])
 def test_conv3x3(ops, n, cin, cout, h, w, up, pad, relu):
     g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
