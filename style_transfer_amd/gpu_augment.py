@@ -40,6 +40,7 @@ class GpuAugment:
         self.sharpness_factor, self.sharpness_p, self.flip_p = sharpness_factor, sharpness_p, flip_p
         self.jitter = {"brightness": brightness, "contrast": contrast, "saturation": saturation, "hue": hue}
         self.generator = torch.Generator().manual_seed(seed)
+        self._noise_generators = {}       # device -> torch.Generator for the Gaussian noise field (seeded from `seed`)
 
     @classmethod
     def for_content(cls, grayscale: bool = False, seed: int = 0) -> "GpuAugment":
@@ -109,8 +110,12 @@ class GpuAugment:
             step("st_aug_rotate", lambda a, b: lib.st_aug_rotate(a, b, _f(angle), n, c, h, w, s()))
         if self.noise is not None:                                              # train.py:131 (style only)
             if noise_field is None:
+                gen = self._noise_generators.get(dev)
+                if gen is None:
+                    gen = self._noise_generators[dev] = torch.Generator(device=dev)
+                    gen.manual_seed(self.generator.initial_seed() + 0x9E3779B1)
                 std = sigma.clamp_min(0).view(n, 1, 1, 1)
-                noise_field = torch.randn((n, c, h, w), device=dev) * std + float(self.noise["mean"])
+                noise_field = torch.randn((n, c, h, w), device=dev, generator=gen) * std + float(self.noise["mean"])
             nf = noise_field.to(dev).contiguous()
             step("st_aug_gaussian_noise",
                  lambda a, b: lib.st_aug_gaussian_noise(a, _f(nf), _f(sigma), b, _f(ws), n, c * h * w, s()))

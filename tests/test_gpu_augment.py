@@ -167,6 +167,12 @@ def test_draws_are_reproducible_and_the_call_uses_them():
     a, b = GpuAugment.for_content(seed=3), GpuAugment.for_content(seed=3)
     torch.testing.assert_close(a(x), b(x), rtol=0, atol=0)
     assert not torch.equal(a(x), b.__class__.for_content(seed=4)(x))
+    # the style pipeline's Gaussian noise field comes from the augmenter's own seeded device generator too
+    s1, s2 = GpuAugment.for_style(seed=9), GpuAugment.for_style(seed=9)
+    torch.manual_seed(123)
+    y1 = s1(x)
+    torch.manual_seed(456)
+    torch.testing.assert_close(s2(x), y1, rtol=0, atol=0)
 
 
 def test_trainer_applies_the_gpu_augmentation_to_every_batch(tmp_path, monkeypatch):
