@@ -9,12 +9,11 @@ Which image gets which transform, and every factor, is drawn per image on the HO
 ``torch.Generator`` (one small host-to-device copy per batch); the draws follow the same distributions as the
 reference's transforms (probabilities, ranges, a uniformly random order of the four ColorJitter adjustments) but not
 its RNG streams (torch global + numpy inside worker processes), which no implementation outside those processes can
-reproduce.  ``params=`` replays explicit draws -- the tests compare every transform with the CPU restatement
-(transforms.py) on identical parameters.
+reproduce.  ``params=`` replays explicit draws -- tests/test_gpu_augment.py compares every transform and both whole
+pipelines with the CPU restatement (transforms.py) on identical parameters.
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, Optional
 
 import torch
@@ -127,25 +126,3 @@ class GpuAugment:
                  lambda a, b: lib.st_aug_color_jitter_slot(a, b, _i(cd), _f(pr), _f(ws), n, h * w, s()))
         step("st_aug_hflip", lambda a, b: lib.st_aug_hflip(a, b, _i(flip), n, c, h, w, s()))
         return state["cur"]
-
-
-def reference_apply(img: torch.Tensor, i: int, params: Dict[str, torch.Tensor], aug: GpuAugment,
-                    noise_field: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """The same transforms on ONE image [3, h, w] with the CPU restatement (transforms.py) and the explicit draws
-    ``params`` -- the checker of tests/test_gpu_augment.py."""
-    from . import transforms as T
-    img = img.cpu()
-    if aug.grayscale:
-        img = T.RGBToGrayscaleStacked(True)(img)
-    if aug.rotation_degrees:
-        img = T.rotate(img, float(params["angle_deg"][i]))
-    if aug.noise is not None and float(params["noise_sigma"][i]) >= 0:
-        img = T.add_noise(img, noise_field[i].permute(1, 2, 0).double().cpu().numpy())
-    if float(params["sharp_factor"][i]) >= 0:
-        img = T.adjust_sharpness(img, float(params["sharp_factor"][i]))
-    jp = params["jitter_param"][i]
-    val = lambda k: None if math.isnan(float(jp[k])) else float(jp[k])            # noqa: E731
-    img = T.color_jitter(img, [int(v) for v in params["jitter_order"][i]], val(0), val(1), val(2), val(3))
-    if int(params["flip"][i]):
-        img = img.flip(-1)
-    return img

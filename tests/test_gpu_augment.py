@@ -10,10 +10,30 @@ import torch
 
 from style_transfer_amd import _lib
 from style_transfer_amd import transforms as T
-from style_transfer_amd.gpu_augment import GpuAugment, reference_apply
+from style_transfer_amd.gpu_augment import GpuAugment
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+def reference_apply(img, i, params, aug, noise_field=None):
+    """The transforms of a GpuAugment on ONE image [3, h, w] with the CPU restatement (transforms.py) and the explicit
+    draws ``params``: the checker of the whole-pipeline test."""
+    img = img.cpu()
+    if aug.grayscale:
+        img = T.RGBToGrayscaleStacked(True)(img)
+    if aug.rotation_degrees:
+        img = T.rotate(img, float(params["angle_deg"][i]))
+    if aug.noise is not None and float(params["noise_sigma"][i]) >= 0:
+        img = T.add_noise(img, noise_field[i].permute(1, 2, 0).double().cpu().numpy())
+    if float(params["sharp_factor"][i]) >= 0:
+        img = T.adjust_sharpness(img, float(params["sharp_factor"][i]))
+    jp = params["jitter_param"][i]
+    val = lambda k: None if math.isnan(float(jp[k])) else float(jp[k])            # noqa: E731
+    img = T.color_jitter(img, [int(v) for v in params["jitter_order"][i]], val(0), val(1), val(2), val(3))
+    if int(params["flip"][i]):
+        img = img.flip(-1)
+    return img
 
 
 def batch(n, h, w, seed=0):

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Do CU-masked streams (hipExtStreamCreateWithCUMask) let a chain of tiny kernels (the eigensolver) run NEXT TO
-chip-filling convolutions?  Times a conv chain and an eigen chain alone and together, for several mask layouts."""
+chip-filling convolutions?  Times a conv chain and an eigen chain alone and together, for several mask layouts.
+
+Outcome on the MI355X box (round 2): two PLAIN streams already overlap the two chains (13.6 ms + 5.7 ms alone, 14.9 ms
+together); a 16-CU mask in the low bits sits in one XCD and slows the convolutions by a third (18.3 ms) without
+helping; the second pair of masked streams could not be created (hipExtStreamCreateWithCUMask -> 2: the process's four
+hardware queues were taken).  CU masks are not used by the library; the lanes of streams.py are."""
 import ctypes
 import os
 import sys
