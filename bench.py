@@ -541,7 +541,10 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
     def one():
         if graphed is not None:
             return graphed(content, style)      # 3 eager warm-up calls, capture, then replays (all before the timed loop)
-        return tr.optimize_step(step, opt, bucket, content, style)
+        # Gram variant: the trainer's one-batch lookahead (Trainer.train) -- the NEXT batch's weight-independent
+        # forward is issued under this batch's eigen-decompositions; here the next batch is the same synthetic pair,
+        # its front is recomputed every step like any other batch's
+        return tr.optimize_step(step, opt, bucket, content, style, prefetch=(content, style) if use_vincent else None)
 
     from style_transfer_amd import precision
     steps, warmup = args.train_steps, args.train_warmup
@@ -559,7 +562,9 @@ def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: in
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "scaling": "weak",
             "dtype": compute, "style_loss": "VincentStyleLoss (covariance MFMA + eigh)" if use_vincent
             else "AdaINStyleLoss (mean/std)",
-            "launch": ("eager launches" if graphed is None else "one HIP graph replay per step (GraphedStep)"
+            "launch": (("eager launches" + (", next batch's weight-independent forward issued under the "
+                                            "eigen-decompositions (one-batch lookahead)" if use_vincent else ""))
+                       if graphed is None else "one HIP graph replay per step (GraphedStep)"
                        if not tr.dp_active else "three HIP graph replays per step around the two eager all-reduces "
                                                 "(GraphedStep, data parallel)"),
             "config": {"workload": ("BASELINE configs[2]: " if (compute, tb, s) == ("f32", 8, 256) else "") +

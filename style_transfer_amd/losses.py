@@ -445,8 +445,16 @@ class VincentStyleLoss(nn.Module):
     def _side_stream(self, key):
         """Side stream number ``key`` (0 .. LANES-1) of the current device: streams that were MEASURED to overlap with
         the current stream and with each other (streams.concurrent_lanes), not merely distinct stream objects."""
+        return self._lanes()[key]
+
+    def _lanes(self):
         from .streams import concurrent_lanes
-        return concurrent_lanes(self.LANES)[key]
+        return concurrent_lanes(self.LANES + 1)       # (high stream priority for the eigen lanes: measured, no effect)
+
+    def prefetch_stream(self):
+        """The one measured-concurrent side stream the eigen jobs do NOT use (main + LANES + this one = the four
+        hardware queues): Trainer runs the next batch's weight-independent forward on it."""
+        return self._lanes()[self.LANES]
 
     @staticmethod
     def _groups(feats):
@@ -464,17 +472,20 @@ class VincentStyleLoss(nn.Module):
     #: and the main stream share a queue).  Splitting the widest group's two layers over two lanes instead of
     #: stacking them: 70.5 ms (two rocSOLVER chains of ~2000 dependent launches each slow each other down far more
     #: than stacking costs).
-    LANES = int(os.environ.get("ST_VINCENT_LANES", "3"))
+    #: Two lanes for the eigen jobs (47.4 ms; three: 47.0), so that a fourth queue stays free for prefetch_stream().
+    LANES = int(os.environ.get("ST_VINCENT_LANES", "2"))
 
     @torch.no_grad()
-    def prepare_targets(self, target_feats):
+    def prepare_targets(self, target_feats, inline: bool = False):
         """Style-image side of every layer; returns an opaque list for ``forward_multi``.  Work is issued on side
-        streams and NOT waited for here (one stacked call per group; lanes as in forward_multi)."""
+        streams and NOT waited for here (one stacked call per group; lanes as in forward_multi).  ``inline``: on the
+        CURRENT stream instead (a caller that is itself a side stream: the trainer's prefetch of the next batch)."""
         cur = torch.cuda.current_stream()
         prepared = []
         for g, (c, idxs) in enumerate(self._groups(target_feats)):
-            st = self._side_stream(min(g, self.LANES - 1))
-            st.wait_stream(cur)
+            st = cur if inline else self._side_stream(min(g, self.LANES - 1))
+            if st is not cur:
+                st.wait_stream(cur)
             with torch.cuda.stream(st):
                 moments = [self.calc_2_moments(target_feats[i]) for i in idxs]
                 mean_stl = [m for m, _ in moments]
@@ -486,8 +497,10 @@ class VincentStyleLoss(nn.Module):
             prepared.append((c, idxs, mean_stl, root, tr, st))
         return prepared
 
-    def forward_multi(self, input_feats, prepared):
-        """Sum over the layers of ``forward(input_feats[i], target_i)`` given ``prepare_targets(targets)``."""
+    def forward_multi(self, input_feats, prepared, on_jobs_issued=None):
+        """Sum over the layers of ``forward(input_feats[i], target_i)`` given ``prepare_targets(targets)``.
+        ``on_jobs_issued``: called after every eigen job has been issued on its lane and BEFORE the current stream is
+        made to wait for them -- the place to put independent work on another stream (Trainer's prefetch)."""
         cur = torch.cuda.current_stream()
         moments = [self.calc_2_moments(f) for f in input_feats]          # MFMA covariances, main stream
         nb = int(input_feats[0].shape[0])
@@ -508,6 +521,8 @@ class VincentStyleLoss(nn.Module):
                     parts.append((dist.mean() * self.scale_factor, st))
             for t in (root, tr, *mean_stl, *(moments[i][k] for i in idxs for k in (0, 1))):
                 t.record_stream(st)
+        if on_jobs_issued is not None:
+            on_jobs_issued()
         total = None
         for val, st in parts:
             cur.wait_stream(st)

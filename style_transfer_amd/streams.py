@@ -33,28 +33,24 @@ def _pair_ms(a: torch.cuda.Stream, b: torch.cuda.Stream) -> float:
     return (time.perf_counter() - t0) * 1e3
 
 
-def concurrent_lanes(n: int, main: torch.cuda.Stream = None) -> List[torch.cuda.Stream]:
+def concurrent_lanes(n: int, main: torch.cuda.Stream = None, priorities=None) -> List[torch.cuda.Stream]:
     """``n`` side streams of the current device that overlap with ``main`` (default: the current stream) and with each
     other, as far as the hardware queues allow (fewer distinct queues than asked for: the list is filled up with
-    streams that share one).  Cached per (device, main stream, n).  Must not be called under stream capture."""
+    streams that share one).  ``priorities``: one torch stream priority per lane (-1 high, 0 normal; default all
+    normal).  Cached per (device, main stream, n, priorities).  Must not be called under stream capture."""
     main = main or torch.cuda.current_stream()
-    key = (torch.cuda.current_device(), main.cuda_stream, n)
+    prios = tuple(priorities) if priorities is not None else (0,) * n
+    assert len(prios) == n
+    key = (torch.cuda.current_device(), main.cuda_stream, n, prios)
     if key in _CACHE:
         return _CACHE[key]
-    cands = [torch.cuda.Stream() for _ in range(max(CANDIDATES, n))]
     _pair_ms(main, main)                                            # warm-up (first launch of the spin kernel)
     single = min(_pair_ms(main, main) for _ in range(3))
     overlaps = lambda a, b: min(_pair_ms(a, b) for _ in range(2)) < 1.5 * single      # noqa: E731  (serial: 2 x single)
     lanes: List[torch.cuda.Stream] = []
-    for c in cands:
-        if len(lanes) == n:
-            break
-        if overlaps(c, main) and all(overlaps(c, l) for l in lanes):
-            lanes.append(c)
-    for c in cands:                                                 # not enough distinct queues: share
-        if len(lanes) == n:
-            break
-        if c not in lanes:
-            lanes.append(c)
+    for prio in prios:
+        cands = [torch.cuda.Stream(priority=prio) for _ in range(CANDIDATES)]
+        pick = next((c for c in cands if overlaps(c, main) and all(overlaps(c, l) for l in lanes)), None)
+        lanes.append(pick if pick is not None else cands[0])        # no free queue left: share one
     _CACHE[key] = lanes
     return lanes

@@ -158,13 +158,15 @@ class StyleTransferStep:
         self.norm = Normalize(IMAGENET_MEAN, IMAGENET_STD)
 
     def partial_losses(self, content_features, style_features, stylized_outputs, style_imgs, content_imgs,
-                       prepared_style=None):
+                       prepared_style=None, on_style_jobs_issued=None):
         """First stage of Trainer.compute_loss: (content, style, variation, q[2]) where q = the local sums under
         the sqrt of the two Hellinger terms (stylised vs style, stylised vs content).  ``prepared_style``: the
-        style-image side of VincentStyleLoss computed ahead (``prepare_targets``, side streams)."""
+        style-image side of VincentStyleLoss computed ahead (``prepare_targets``, side streams);
+        ``on_style_jobs_issued``: called once its stylised-side jobs are on their streams (see forward_multi)."""
         loss_content = sum(self.content_loss(f['model_output'], f['orginal']) for f in content_features)
         if prepared_style is not None:
-            loss_style = self.style_loss.forward_multi([f['model_output'] for f in style_features], prepared_style)
+            loss_style = self.style_loss.forward_multi([f['model_output'] for f in style_features], prepared_style,
+                                                       on_jobs_issued=on_style_jobs_issued)
         else:
             loss_style = sum(self.style_loss(f['model_output'], f['orginal']) for f in style_features)
         variation_loss = self.variation_loss(stylized_outputs)
@@ -191,16 +193,21 @@ class StyleTransferStep:
         batch = stylized_outputs.shape[0] if global_batch is None else global_batch
         return self.combine(partials, allreduce_q(partials[3]), batch)
 
-    def forward_partials(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor):
+    # The forward in two halves.  ``front``: everything that does not depend on a TRAINED weight -- Normalize of the
+    # originals, their loss-VGG passes, the frozen encoder on content and style, the style-image side of
+    # VincentStyleLoss.  ``rest``: AdaIN (trainable eps), decoder, the stylised image's loss-VGG pass, the losses.
+    # The split is what lets a Gram-loss step compute the NEXT batch's front while this batch's eigen-decompositions
+    # (a 13 ms chain of tiny launches that leaves the chip idle) are running: Trainer.optimize_step(prefetch=...).
+    def front(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, inline_targets: bool = False) -> dict:
         # The style image's loss-VGG pass goes FIRST: with VincentStyleLoss everything that depends on the style
-        # image alone (covariances, eigh(cov_stl), root_cov_stl) is then issued on side streams and overlaps the
-        # encoder / decoder / loss-VGG convolutions below.  Same values as the reference's order (trainer.py:453).
-        style_n = self.norm(style_imgs)
+        # image alone (covariances, cov_stl^(1/2)) is then issued on side streams and overlaps the encoder
+        # convolutions below.  Same values as the reference's order (trainer.py:453).
         with torch.no_grad():
+            style_n = self.norm(style_imgs)
             org_style = self.loss_vgg.forward_multi(style_n, [self.style_layers_idx])[0]
-        prepared_style = self.style_loss.prepare_targets(org_style) if hasattr(self.style_loss, "prepare_targets") \
-            else None
-        with torch.no_grad():                              # frozen encoder: forward only
+            prepared_style = self.style_loss.prepare_targets(org_style, inline=inline_targets) \
+                if hasattr(self.style_loss, "prepare_targets") else None
+            # frozen encoder: forward only
             if content_imgs.shape == style_imgs.shape:
                 # one pass over [content; style]: same kernels, same per-image results (no cross-image op in
                 # the encoder), twice the grid -- small training batches fill the chip better
@@ -210,17 +217,25 @@ class StyleTransferStep:
             else:
                 encode_Cfeatures = self.encoder(content_imgs)
                 encode_Sfeatures = self.encoder(style_imgs)
-        transformed_features = self.transformer(encode_Cfeatures, encode_Sfeatures, alpha=1.0)   # trainer.py:433-434
-        decode_imgs = self.decoder(transformed_features)
-        content_n = self.norm(content_imgs)
-        decode_n = self.norm(decode_imgs)
-        with torch.no_grad():
+            content_n = self.norm(content_imgs)
             org_content = self.loss_vgg.forward_multi(content_n, [self.content_layers_idx])[0]
+        return {"style_n": style_n, "content_n": content_n, "org_style": org_style, "org_content": org_content,
+                "prepared_style": prepared_style, "encode_C": encode_Cfeatures, "encode_S": encode_Sfeatures}
+
+    def rest(self, fr: dict, on_style_jobs_issued=None):
+        transformed_features = self.transformer(fr["encode_C"], fr["encode_S"], alpha=1.0)   # trainer.py:433-434
+        decode_imgs = self.decoder(transformed_features)
+        decode_n = self.norm(decode_imgs)
         gen_content, gen_style = self.loss_vgg.forward_multi(decode_n, [self.content_layers_idx, self.style_layers_idx])
         # the reference indexes the getter's layer-ordered outputs by position (trainer.py:448-457)
-        content_features = [{"orginal": o, "model_output": g} for o, g in zip(org_content, gen_content)]
-        style_features = [{"orginal": o, "model_output": g} for o, g in zip(org_style, gen_style)]
-        return self.partial_losses(content_features, style_features, decode_n, style_n, content_n, prepared_style)
+        content_features = [{"orginal": o, "model_output": g} for o, g in zip(fr["org_content"], gen_content)]
+        style_features = [{"orginal": o, "model_output": g} for o, g in zip(fr["org_style"], gen_style)]
+        return self.partial_losses(content_features, style_features, decode_n, fr["style_n"], fr["content_n"],
+                                   fr["prepared_style"], on_style_jobs_issued)
+
+    def forward_partials(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, front: Optional[dict] = None,
+                         on_style_jobs_issued=None):
+        return self.rest(front if front is not None else self.front(content_imgs, style_imgs), on_style_jobs_issued)
 
     def forward_losses(self, content_imgs: torch.Tensor, style_imgs: torch.Tensor, global_batch: Optional[int] = None):
         partials = self.forward_partials(content_imgs, style_imgs)
@@ -614,11 +629,47 @@ class Trainer:
 
     # The step in three phases with the two data-parallel exchanges between them (GraphedStep replays each phase
     # from its own HIP graph; eager steps call them back to back).
-    def step_forward(self, step: StyleTransferStep, bucket: GradBucket, content_imgs, style_imgs):
-        """zero_grad (one memset of the flat bucket) + the forward up to the per-rank Hellinger sums."""
+    def step_forward(self, step: StyleTransferStep, bucket: GradBucket, content_imgs, style_imgs, prefetch=None):
+        """zero_grad (one memset of the flat bucket) + the forward up to the per-rank Hellinger sums.
+        ``prefetch``: the NEXT batch (content, style), see optimize_step."""
         bucket.zero()
         step.decoder._packed.direct_grads = True       # weight gradients are written straight into the bucket
-        return step.forward_partials(content_imgs, style_imgs)
+        front = self._take_front(content_imgs, style_imgs)
+        hook = None
+        if prefetch is not None and hasattr(step.style_loss, "prefetch_stream"):
+            hook = lambda: self._prefetch_front(step, *prefetch)        # noqa: E731
+        return step.forward_partials(content_imgs, style_imgs, front, hook)
+
+    # ---- the next batch's weight-independent forward, computed under this batch's eigen-decompositions -----------
+    def _prefetch_front(self, step: StyleTransferStep, content_imgs, style_imgs):
+        """Called by VincentStyleLoss.forward_multi once this step's eigen jobs are on their lanes: StyleTransferStep.
+        front of the next batch on the free side stream (it waits for everything issued on the current stream so far,
+        i.e. for the batch's tensors, and for nothing the lanes do)."""
+        cur = torch.cuda.current_stream()
+        pf = step.style_loss.prefetch_stream()
+        pf.wait_stream(cur)
+        with torch.cuda.stream(pf):
+            fr = step.front(content_imgs, style_imgs, inline_targets=True)
+        self._front_next = (content_imgs, style_imgs, fr, pf)
+
+    def _take_front(self, content_imgs, style_imgs):
+        """The prefetched front of exactly these batch tensors, made safe for the current stream; else None."""
+        nxt, self._front_next = getattr(self, "_front_next", None), None
+        if nxt is None or nxt[0] is not content_imgs or nxt[1] is not style_imgs:
+            return None
+        _, _, fr, pf = nxt
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(pf)
+
+        def claim(v):                                   # allocated on the prefetch stream, used (and freed) here
+            if isinstance(v, torch.Tensor):
+                v.record_stream(cur)
+            elif isinstance(v, (list, tuple)):
+                for w in v:
+                    claim(w)
+        for v in fr.values():
+            claim(v)
+        return fr
 
     def step_backward(self, step: StyleTransferStep, partials, q_sum, global_batch: int):
         """Rest of compute_loss from the batch-wide q, then backward into the bucket (trainer.py:472)."""
@@ -646,9 +697,15 @@ class Trainer:
             for p, old, m in zip(eps_params, before, masks):
                 p.copy_(torch.where(m, old, p))
 
-    def optimize_step(self, step: StyleTransferStep, optimizer, bucket: GradBucket, content_imgs, style_imgs):
-        """zero_grad / backward / [grad all-reduce] / [AdaIN grad clamp] / optimizer.step (trainer.py:471-473, 392-394)."""
-        partials = self.step_forward(step, bucket, content_imgs, style_imgs)
+    def optimize_step(self, step: StyleTransferStep, optimizer, bucket: GradBucket, content_imgs, style_imgs,
+                      prefetch=None):
+        """zero_grad / backward / [grad all-reduce] / [AdaIN grad clamp] / optimizer.step (trainer.py:471-473, 392-394).
+        ``prefetch`` = the NEXT batch's (content, style) device tensors, or None.  With VincentStyleLoss the part of
+        that batch's forward which touches no trained weight (Normalize, both loss-VGG passes over the originals, the
+        frozen encoder, cov_stl^(1/2)) is issued on a side stream while THIS batch's eigen-decompositions run -- a
+        13 ms chain of tiny launches that leaves the chip idle -- and is picked up when the next call gets exactly
+        those tensors.  Same values as computing it in the next step; other style losses ignore the argument."""
+        partials = self.step_forward(step, bucket, content_imgs, style_imgs, prefetch)
         q_sum = partials[3]
         if self.dp_active:
             dist = _dist()
@@ -711,12 +768,30 @@ class Trainer:
             transformer.train()
             if self.do_decoder_train:
                 decoder.train()
-            for step, batch in enumerate(train_loader):
-                content_imgs = batch['content_image'].to(self.device, non_blocking=True).contiguous()
-                style_imgs = batch['style_image'].to(self.device, non_blocking=True).contiguous()
+            # one batch of lookahead: with VincentStyleLoss the next batch's weight-independent forward is issued under
+            # this batch's eigen-decompositions (optimize_step(prefetch=...)); HIP-graph replay has no such stall
+            lookahead = self.use_VincentStyleLoss and not self.graph_capable()
+
+            def on_device(batch):
+                c_ = batch['content_image'].to(self.device, non_blocking=True).contiguous()
+                s_ = batch['style_image'].to(self.device, non_blocking=True).contiguous()
                 if self.gpu_augment is not None:
-                    content_imgs, style_imgs = self.gpu_augment[0](content_imgs), self.gpu_augment[1](style_imgs)
-                losses = run_step(content_imgs, style_imgs)
+                    c_, s_ = self.gpu_augment[0](c_), self.gpu_augment[1](s_)
+                return c_, s_
+            batches = iter(train_loader)
+            nxt = next(batches, None)
+            nxt = on_device(nxt) if nxt is not None else None
+            step = -1
+            while nxt is not None:
+                step += 1
+                content_imgs, style_imgs = nxt
+                nxt = next(batches, None)
+                nxt = on_device(nxt) if nxt is not None else None
+                if lookahead:
+                    losses = self.optimize_step(step_engine, transformer_optimizer, bucket, content_imgs, style_imgs,
+                                                prefetch=nxt)
+                else:
+                    losses = run_step(content_imgs, style_imgs)
                 completed_step += step                                          # trainer.py:475 (sic: index, not 1)
                 row = torch.stack([l.detach().reshape(()) for l in losses])
                 sums += row.double()

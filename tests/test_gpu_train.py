@@ -275,3 +275,47 @@ def test_clamped_eps_parameters_are_not_touched_by_the_optimizer(eps_limit, move
         assert all(not torch.equal(a, b) for a, b in zip(after, before))
     else:
         assert all(torch.equal(a, b) for a, b in zip(after, before))
+
+
+def test_gram_step_with_lookahead_walks_the_same_trajectory():
+    """optimize_step(prefetch=next batch) with VincentStyleLoss: the next batch's weight-independent forward (Normalize,
+    loss-VGG passes over the originals, frozen encoder, cov_stl^(1/2)) runs on a side stream under this batch's
+    eigen-decompositions.  Same kernels on the same data: losses and weights must equal the plain sequence."""
+    import warnings
+    from style_transfer_amd.trainer import GradBucket, Trainer
+
+    def run(lookahead):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tr = Trainer({"train": []}, output_dir="/tmp/st_la_test", num_train_epochs=1, per_device_batch_size=2,
+                         learning_rate=1e-3, alpha=1.0, beta=10.0, gamma=1.0, delta=10.0, eps=0.1, do_decoder_train=True,
+                         optim_name={"optim_name": "adam"}, use_VincentStyleLoss=True, content_layers_idx=[21],
+                         style_layers_idx=[2, 7, 14, 19, 25], encoder_weights=R.make_encoder_state(0),
+                         vgg_weights=R.make_loss_vgg_state(2, upto=25), device="cuda")
+            encoder, decoder, transformer, loss_vgg = tr.build_model()
+            decoder.load_state_dict(R.make_decoder_state(1))
+            params = tr.trainable_parameters(transformer, decoder)
+            opt = tr.get_optimizer("adam", params, 1e-3, {})
+            step = tr.make_step(encoder, decoder, transformer, loss_vgg)
+        bucket = GradBucket(params)
+        g = torch.Generator().manual_seed(77)
+        batches = [(torch.rand(2, 3, 64, 64, generator=g).cuda(), torch.rand(2, 3, 64, 64, generator=g).cuda())
+                   for _ in range(5)]
+        out = []
+        for i, (c, s) in enumerate(batches):
+            nxt = batches[i + 1] if lookahead and i + 1 < len(batches) else None
+            losses = tr.optimize_step(step, opt, bucket, c, s, prefetch=nxt)
+            if lookahead and nxt is not None:
+                assert tr._front_next is not None and tr._front_next[0] is nxt[0]       # the prefetch was issued
+            out.append(torch.stack([l.detach().reshape(()) for l in losses]).cpu())
+        torch.cuda.synchronize()
+        assert tr._front_next is None
+        w = torch.cat([p.detach().flatten() for p in list(decoder.parameters()) + list(transformer.parameters())]).cpu()
+        return torch.stack(out), w
+    l0, w0 = run(False)
+    l1, w1 = run(True)
+    torch.testing.assert_close(l1, l0, rtol=1e-6, atol=0)
+    torch.testing.assert_close(w1, w0, rtol=1e-6, atol=1e-9)
+    # a prefetched front that does not belong to the batch handed in is dropped, not used
+    l2, _ = run(False)
+    torch.testing.assert_close(l2, l0, rtol=0, atol=0)

@@ -1,10 +1,9 @@
-"""A few Gram-variant (VincentStyleLoss) training steps at BASELINE configs[2] -- profiling target."""
-import sys, warnings, contextlib, torch
-import os
+"""Where the Gram-variant step spends its time: front (weight-independent forward), rest of the forward up to the
+point where the eigen jobs are issued, the eigen wait, backward + update.  HIP events on the main stream."""
+import sys, os, warnings, contextlib, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ref_ops as R
 from style_transfer_amd.trainer import GradBucket, Trainer
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dev = torch.device("cuda")
 with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):
     warnings.simplefilter("ignore")
@@ -21,10 +20,25 @@ with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):
 bucket = GradBucket(params)
 g = torch.Generator().manual_seed(1)
 c = torch.rand(8, 3, 256, 256, generator=g).to(dev); s = torch.rand(8, 3, 256, 256, generator=g).to(dev)
-import time
-for i in range(steps):
-    if i == steps - 2:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-    tr.optimize_step(step, opt, bucket, c, s, prefetch=None if os.environ.get('ST_NO_PREFETCH') else (c, s))
+for _ in range(4):
+    tr.optimize_step(step, opt, bucket, c, s)
 torch.cuda.synchronize()
-print(f"{(time.perf_counter() - t0) / 2 * 1e3:.2f} ms/step")
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+ev[0].record()
+fr = step.front(c, s)
+ev[1].record()
+bucket.zero()
+marks = {}
+def hook():
+    ev[2].record()
+partials = step.rest(fr, hook)
+ev[3].record()
+losses = tr.step_backward(step, partials, partials[3], 8)
+ev[4].record()
+tr.step_update(step, opt, bucket)
+ev[5].record()
+torch.cuda.synchronize()
+names = ["front", "rest of forward up to eigen jobs issued", "eigen wait + loss tail", "backward", "update"]
+for i, n in enumerate(names):
+    print(f"{n:45s} {ev[i].elapsed_time(ev[i + 1]):7.2f} ms")
+print(f"{'total':45s} {ev[0].elapsed_time(ev[5]):7.2f} ms")
