@@ -133,6 +133,27 @@ int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, const float* 
 int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y, int y_g8,
                            int n, int cin, int hin, int win, int cout, int upsample2x, int pad_mode, int relu,
                            int pool, st_stream_t stream);
+/* bf16 mode, data gradient of a ZERO-padded layer inside a G8 chain: the backward of the loss VGG
+ * (loss.backward() of trainer.py:472 through the extractors of trainer.py:165-199, 446-457).  The same implicit GEMM
+ * on w_packed_t (st_conv3x3_pack_weights_bf16 with transpose_flip), no bias, no activation.  dy [n][cout][h][w] is
+ * fp32 NCHW or (dy_g8) G8; a G8 dy must ALREADY carry this layer's ReLU gate (its producer applied it: dx_gate_g8 of
+ * the launch before, or st_grad_join_g8).  dx [n][cin][h][w] is fp32 NCHW or (dx_g8) G8; dx_gate_g8 (G8, the shape
+ * of dx, needs dx_g8; may be NULL) = this layer's INPUT activation: dx is stored as 0 where it is <= 0, i.e. it
+ * leaves the launch gated for the layer below.  Bit-identical to st_conv3x3_dgrad_bf16 on the same values (the G8
+ * rounding is the one the next launch's staging applies to an fp32 gradient). */
+int st_conv3x3_dgrad_bf16_g8(const void* dy, int dy_g8, const void* w_packed_t, void* dx, int dx_g8,
+                             const void* dx_gate_g8, int n, int cout, int h, int w, int cin, st_stream_t stream);
+/* The gradient that reaches a CAPTURED layer output (a loss tap of trainer.py:446-457, fp32 NCHW) or the input of
+ * a max pool, formed in one pass as the G8 operand of that layer's st_conv3x3_dgrad_bf16_g8:
+ *     out_g8 = [x_gate > 0] * (chain + add_post) + add_pre
+ * chain: gradient from the layer above, fp32 [n][c][h][w]; or chain_pooled: fp32 [n][c][h/2][w/2], the gradient
+ * w.r.t. the floor-mode 2x2 max pool of x_gate (torchvision vgg19 'M'), routed like st_maxpool2x2_bwd (h, w even);
+ * add_post / add_pre: loss gradients w.r.t. the post- / pre-ReLU capture (IntermediateLayerGetter returns the last
+ * requested index before its in-place ReLU, trainer.py:165-199); x_gate: the captured tensor (NULL: no gate).
+ * Every input is optional (at least one source); c % 8 == 0.  Same values as st_maxpool2x2_bwd / fp32 add /
+ * st_relu_bwd followed by the bf16 rounding of the data-gradient kernel's staging. */
+int st_grad_join_g8(const float* chain, const float* chain_pooled, const float* x_gate, const float* add_post,
+                    const float* add_pre, void* out_g8, int n, int c, int h, int w, st_stream_t stream);
 /* The same for the bf16x3 mode (weights from st_conv3x3_pack_weights_bf16x3): a "G8" activation is the hi/lo pair
  * form bf16 [n][c/8][2][h][w][8] with part 0 = bf16(v) and part 1 = bf16(v - part 0) -- the split the kernels apply
  * to an fp32 activation, done once by the producing layer; as many bytes as fp32, staged by LDS-DMA.  Bit-identical

@@ -73,7 +73,21 @@ struct ConvParams {
   int ntiles;              // PERSIST kernels: total (pixel tile, channel tile) pairs, walked with stride gridDim.x
   int vec_store;           // ldo % 4 == 0 and y 16-B aligned: 16-B-per-lane epilogue stores
   int ablate;              // debug only (ST_BF16_ABLATE): 1 skip MFMA, 2 skip X staging, 4 skip W DMA
+  // G8 output only (st_conv3x3_dgrad_bf16_g8): a G8 tensor of the OUTPUT's shape; the result is stored as 0 where
+  // it is <= 0 -- the ReLU gate of the layer that produced this kernel's output tensor's forward twin
+  const u32x4* ogate = nullptr;
 };
+
+// 8 bf16 lanes of `v` kept where the same lane of `g` is > 0 (bit test: 0x0001 .. 0x7f80 = positive, incl. +inf)
+__device__ __forceinline__ u32x4 gate_g8(u32x4 v, u32x4 g) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned lo = g[k] & 0xffffu, hi = g[k] >> 16;
+    const unsigned m = ((lo - 1u) < 0x7f80u ? 0x0000ffffu : 0u) | ((hi - 1u) < 0x7f80u ? 0xffff0000u : 0u);
+    v[k] &= m;
+  }
+  return v;
+}
 
 template <int MT, int NT, int WM, int WP, bool SPLIT = false>
 struct Cfg {
@@ -610,8 +624,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         const bool ok = cg < cgroups && yy < p.Ho && xs < p.Wo;                                       \
         const size_t o = (size_t(b) * cgroups + cg) * NPT * plane_y + size_t(yy) * Wy + xs;           \
         _Pragma("unroll") for (int part = 0; part < NPT; ++part) {                                    \
-          const u32x4 v = patch16[part * 128 + li * 4 + q];                                           \
-          if (ok) yg[o + part * plane_y] = v;                                                         \
+          u32x4 v = patch16[part * 128 + li * 4 + q];                                                 \
+          if (ok) {                                                                                   \
+            if (!SPLIT && p.ogate) v = gate_g8(v, p.ogate[o]);                                        \
+            yg[o + part * plane_y] = v;                                                               \
+          }                                                                                           \
         }                                                                                             \
       }                                                                                               \
     } else {                                                                                          \
@@ -936,13 +953,16 @@ extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, co
 
 static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
                                int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
-                               int pad_mode, int relu, int pool, st_stream_t stream, bool split) {
+                               int pad_mode, int relu, int pool, st_stream_t stream, bool split,
+                               const void* ogate = nullptr) {
   ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16_g8: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
              "st_conv3x3_fwd_bf16_g8: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
   ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO, "st_conv3x3_fwd_bf16_g8: bad pad_mode %d",
              pad_mode);
   ST_REQUIRE(!(pool && upsample2x), "st_conv3x3_fwd_bf16_g8: pool and upsample2x exclude each other");
+  ST_REQUIRE(!ogate || (y_g8 && !pool && !split && reinterpret_cast<uintptr_t>(ogate) % 16 == 0),
+             "st_conv3x3_dgrad_bf16_g8: an output gate needs a 16-byte aligned G8 gate and a G8 output");
   if (!x_g8 && !y_g8)
     return conv3x3_fwd_bf16_impl((const float*)x, w_packed, bias, (float*)y, n, cin, hin, win, cout, upsample2x,
                                  pad_mode, relu, pool, stream, split);
@@ -953,6 +973,7 @@ static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, co
   ST_REQUIRE((long long)hin * win * 16 < (1LL << 31), "st_conv3x3_fwd_bf16_g8: plane too large");
   ConvParams p;
   p.x = (const float*)x; p.gate = nullptr; p.wp = (const u32x4*)w_packed; p.bias = bias; p.y = (float*)y;
+  p.ogate = (const u32x4*)ogate;
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
   p.up = upsample2x ? 1 : 0;
   p.H = hin << p.up; p.W = win << p.up;
@@ -980,6 +1001,20 @@ extern "C" int st_conv3x3_fwd_bf16x3_g8(const void* x, int x_g8, const void* w_p
                                         int pad_mode, int relu, int pool, st_stream_t stream) {
   return conv3x3_fwd_g8_impl(x, x_g8, w_packed, bias, y, y_g8, n, cin, hin, win, cout, upsample2x, pad_mode, relu,
                              pool, stream, true);
+}
+
+// Data gradient of a ZERO-padded layer inside a G8 chain (the loss VGG's backward, trainer.py:472 through the
+// extractors of :165-199): the same implicit GEMM on the transposed / flipped filter (st_conv3x3_pack_weights_bf16
+// with transpose_flip) with no bias and no activation.  A G8 `dy` must already carry the layer's own ReLU gate (its
+// producer applied it: `dx_gate_g8` of the launch before, or st_grad_join_g8); `dx_gate_g8` zeroes the result
+// where the layer's INPUT activation (G8, the shape of dx) is <= 0, so the G8 result feeds the next launch as is.
+extern "C" int st_conv3x3_dgrad_bf16_g8(const void* dy, int dy_g8, const void* w_packed_t, void* dx, int dx_g8,
+                                        const void* dx_gate_g8, int n, int cout, int h, int w, int cin,
+                                        st_stream_t stream) {
+  ST_REQUIRE(dy && w_packed_t && dx, "st_conv3x3_dgrad_bf16_g8: null pointer");
+  ST_REQUIRE(!dx_gate_g8 || dx_g8, "st_conv3x3_dgrad_bf16_g8: dx_gate_g8 needs a G8 dx");
+  return conv3x3_fwd_g8_impl(dy, dy_g8, w_packed_t, nullptr, dx, dx_g8, n, cout, h, w, cin, 0, ST_PAD_ZERO, 0, 0,
+                             stream, false, dx_gate_g8);
 }
 
 extern "C" int st_conv3x3_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y,

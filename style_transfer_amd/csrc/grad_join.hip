@@ -1,0 +1,190 @@
+// Gradient "joins" of the loss VGG's backward in the bf16 compute mode (trainer.py:472 through the feature
+// extractors of trainer.py:165-199): the data-gradient launches hand each other the gradient in the bf16 channel-group
+// layout G8 (st_conv3x3_dgrad_bf16_g8).  Where a layer's output was CAPTURED (a loss tap, fp32 NCHW) or feeds a max
+// pool, the gradient that reaches it has more than one source and crosses a ReLU; this kernel forms it in ONE pass
+// and writes the G8 operand of the layer's data-gradient launch:
+//
+//     out = gate(x) * (chain + add_post) + add_pre,      gate(x) = [x > 0]
+//
+//   chain      gradient from the next layer: fp32 NCHW of the tap's shape, OR (`chain_pooled`) the gradient w.r.t. the
+//              output of the floor-mode 2x2 max pool that follows the tap, routed to the first maximum of each window
+//              in scan order exactly like st_maxpool2x2_bwd (x = the pool's input);
+//   add_post   the loss gradient w.r.t. the post-ReLU tap;  add_pre  the loss gradient w.r.t. the pre-ReLU tap (the
+//              last index of an IntermediateLayerGetter is captured before the in-place ReLU, loss_network.py);
+//   x          the tap itself (post-ReLU output, or the pre-ReLU tensor: same sign pattern and, where any entry of a
+//              window is positive, the same arg-max); NULL = no gate.
+// Every term is optional.  fp32 sums in this order, one round-to-nearest-even to bf16: the same values the separate
+// max-pool-backward / accumulate / ReLU-backward kernels followed by the data-gradient kernel's staging produce.
+// HBM-bound: 4 B per source element read once, 2 B written.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct JoinParams {
+  const float* chain;
+  const float* chain_pooled;
+  const float* x;
+  const float* add_post;
+  const float* add_pre;
+  u32x4* out;
+  int c, h, w;
+  long long total;   // threads' worth of work items
+};
+
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+  return __builtin_bit_cast(u32x4, b);
+}
+
+// item = (image, channel group, PX consecutive pixels of the flattened plane)
+template <int PX>
+__global__ __launch_bounds__(256) void grad_join_kernel(JoinParams p) {
+  const long long hw = (long long)p.h * p.w;
+  const long long per_plane = hw / PX;
+  const int cgs = p.c >> 3;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < p.total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long pix = (e % per_plane) * PX;
+    const long long t = e / per_plane;
+    const int cg = int(t % cgs);
+    const long long b = t / cgs;
+    const long long base = (b * p.c + cg * 8) * hw + pix;
+    float v[PX][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long off = base + j * hw;
+      float a[PX], g[PX], q[PX], r[PX];
+      if constexpr (PX == 4) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 a4 = p.chain ? *reinterpret_cast<const f32x4*>(p.chain + off) : z;
+        const f32x4 q4 = p.add_post ? *reinterpret_cast<const f32x4*>(p.add_post + off) : z;
+        const f32x4 g4 = p.x ? *reinterpret_cast<const f32x4*>(p.x + off) : z;
+        const f32x4 r4 = p.add_pre ? *reinterpret_cast<const f32x4*>(p.add_pre + off) : z;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = a4[k]; q[k] = q4[k]; g[k] = g4[k]; r[k] = r4[k]; }
+      } else {
+        a[0] = p.chain ? p.chain[off] : 0.f;
+        q[0] = p.add_post ? p.add_post[off] : 0.f;
+        g[0] = p.x ? p.x[off] : 0.f;
+        r[0] = p.add_pre ? p.add_pre[off] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < PX; ++k) {
+        float s = a[k];
+        if (p.add_post) s = p.chain ? s + q[k] : q[k];
+        if (p.x) s = g[k] > 0.f ? s : 0.f;
+        if (p.add_pre) s = (p.chain || p.add_post) ? s + r[k] : r[k];
+        v[k][j] = s;
+      }
+    }
+    u32x4* o = p.out + (b * cgs + cg) * hw + pix;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) o[k] = pack8(v[k]);
+  }
+}
+
+// item = (image, channel group, one 2x2 window of the pool's input); h and w even
+__global__ __launch_bounds__(256) void grad_join_pool_kernel(JoinParams p) {
+  const int ho = p.h >> 1, wo = p.w >> 1;
+  const long long hw = (long long)p.h * p.w, hwo = (long long)ho * wo;
+  const int cgs = p.c >> 3;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < p.total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ox = int(e % wo);
+    long long t = e / wo;
+    const int oy = int(t % ho);
+    t /= ho;
+    const int cg = int(t % cgs);
+    const long long b = t / cgs;
+    const long long win = (long long)(2 * oy) * p.w + 2 * ox;     // first pixel of the window inside a plane
+    float v[4][8];                                                 // window positions 0..3 in scan order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long plane = b * p.c + cg * 8 + j;
+      const long long off = plane * hw + win;
+      const f32x2 x0 = *reinterpret_cast<const f32x2*>(p.x + off);
+      const f32x2 x1 = *reinterpret_cast<const f32x2*>(p.x + off + p.w);
+      const float g = p.chain_pooled[plane * hwo + (long long)oy * wo + ox];
+      const float xs[4] = {x0[0], x0[1], x1[0], x1[1]};
+      float m = xs[0];
+      int arg = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (xs[k] > m || xs[k] != xs[k]) { m = xs[k]; arg = k; }   // st_maxpool2x2_bwd's (= torch's) tie rule
+      float q[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.add_post) {
+        const f32x2 q0 = *reinterpret_cast<const f32x2*>(p.add_post + off);
+        const f32x2 q1 = *reinterpret_cast<const f32x2*>(p.add_post + off + p.w);
+        q[0] = q0[0]; q[1] = q0[1]; q[2] = q1[0]; q[3] = q1[1];
+      }
+      if (p.add_pre) {
+        const f32x2 r0 = *reinterpret_cast<const f32x2*>(p.add_pre + off);
+        const f32x2 r1 = *reinterpret_cast<const f32x2*>(p.add_pre + off + p.w);
+        r[0] = r0[0]; r[1] = r0[1]; r[2] = r1[0]; r[3] = r1[1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float s = arg == k ? g : 0.f;
+        if (p.add_post) s += q[k];
+        s = xs[k] > 0.f ? s : 0.f;
+        if (p.add_pre) s += r[k];
+        v[k][j] = s;
+      }
+    }
+    u32x4* o = p.out + (b * cgs + cg) * hw + win;
+    o[0] = pack8(v[0]);
+    o[1] = pack8(v[1]);
+    o[p.w] = pack8(v[2]);
+    o[p.w + 1] = pack8(v[3]);
+  }
+}
+
+inline int grid_for(long long total) {
+  return (int)std::max<long long>(1, std::min<long long>(st::cdivll(total, 256), 256 * 16));
+}
+
+}  // namespace
+
+extern "C" int st_grad_join_g8(const float* chain, const float* chain_pooled, const float* x_gate,
+                               const float* add_post, const float* add_pre, void* out_g8, int n, int c, int h,
+                               int w, st_stream_t stream) {
+  ST_REQUIRE(out_g8, "st_grad_join_g8: null output");
+  ST_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && c % 8 == 0, "st_grad_join_g8: bad dims n=%d c=%d h=%d w=%d (c %% 8 == 0)",
+             n, c, h, w);
+  ST_REQUIRE(!(chain && chain_pooled), "st_grad_join_g8: chain and chain_pooled exclude each other");
+  ST_REQUIRE(chain || chain_pooled || add_post || add_pre, "st_grad_join_g8: no gradient source");
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(out_g8) % 16 == 0, "st_grad_join_g8: out_g8 must be 16-byte aligned");
+  JoinParams p;
+  p.chain = chain; p.chain_pooled = chain_pooled; p.x = x_gate; p.add_post = add_post; p.add_pre = add_pre;
+  p.out = (u32x4*)out_g8; p.c = c; p.h = h; p.w = w;
+  hipStream_t s = (hipStream_t)stream;
+  const long long hw = (long long)h * w;
+  if (chain_pooled) {
+    ST_REQUIRE(x_gate, "st_grad_join_g8: chain_pooled needs the pool's input in x_gate");
+    ST_REQUIRE(h % 2 == 0 && w % 2 == 0, "st_grad_join_g8: chain_pooled needs even h, w (got %dx%d)", h, w);
+    for (const float* q : {x_gate, add_post, add_pre})
+      ST_REQUIRE(reinterpret_cast<uintptr_t>(q) % 8 == 0, "st_grad_join_g8: 8-byte aligned fp32 tensors expected");
+    p.total = (long long)n * (c / 8) * (hw / 4);
+    hipLaunchKernelGGL(grad_join_pool_kernel, dim3(grid_for(p.total)), dim3(256), 0, s, p);
+    return st::check_launch("st_grad_join_g8");
+  }
+  bool vec = hw % 4 == 0;
+  for (const float* q : {chain, x_gate, add_post, add_pre}) vec = vec && reinterpret_cast<uintptr_t>(q) % 16 == 0;
+  if (vec) {
+    p.total = (long long)n * (c / 8) * (hw / 4);
+    hipLaunchKernelGGL(grad_join_kernel<4>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
+  } else {
+    p.total = (long long)n * (c / 8) * hw;
+    hipLaunchKernelGGL(grad_join_kernel<1>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
+  }
+  return st::check_launch("st_grad_join_g8");
+}

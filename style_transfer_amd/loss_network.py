@@ -12,6 +12,7 @@ that: captured conv outputs are post-ReLU, except when the conv is the final lay
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from collections import OrderedDict
 from typing import Dict, List, Sequence, Union
@@ -152,6 +153,8 @@ class VGG19FeatureExtractor(nn.Module):
         compute = precision.get_compute_dtype()
         if compute in ("bf16", "bf16x3") and not _needs_grad(x):
             return self._forward_multi_g8(x, sets, last_all, need_pre, compute)
+        if compute == "bf16" and self.GRAD_CHAIN and _needs_grad(x):
+            return self._forward_multi_chain(x, sets, last_all)
         pre: Dict[int, torch.Tensor] = {}
         post: Dict[int, torch.Tensor] = {}
         idx = 0
@@ -181,6 +184,23 @@ class VGG19FeatureExtractor(nn.Module):
         for s in sets:
             res.append([pre[i] if (i == max(s) and i in pre) else post[i] for i in s])
         return res
+
+    #: bf16 mode, differentiated pass (the decoded image): one autograd node whose forward AND backward hand
+    #: activations / gradients over in G8 (autograd_vgg.VGGChainFunction); ST_VGG_CHAIN=0: the per-layer graph
+    GRAD_CHAIN = os.environ.get("ST_VGG_CHAIN", "1") != "0"
+
+    def _forward_multi_chain(self, x, sets, last_all):
+        from .autograd_vgg import VGGChainFunction, capture_sets
+        pre, post = capture_sets(self.layout, sets)
+        keys = VGGChainFunction.keys(self.layout, last_all, pre, post)
+        outs = dict(zip(keys, VGGChainFunction.apply(x, self, last_all, frozenset(pre), frozenset(post))))
+
+        def pick(s, i):
+            if i == max(s) and self.layout[i][0] == "conv":
+                return outs[("pre", i)]
+            # a post-ReLU capture belongs to the conv unit it sits in (conv index or its ReLU's index)
+            return outs[("post", i - 1 if self.layout[i][0] == "relu" else i)]
+        return [[pick(s, i) for i in s] for s in sets]
 
     def _forward_multi_g8(self, x, sets, last_all, need_pre, compute):
         """forward_multi without gradients in a bf16 compute mode (the passes over the content and style ORIGINALS,

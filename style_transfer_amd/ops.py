@@ -275,6 +275,59 @@ def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: 
     return dx
 
 
+def conv3x3_dgrad_g8(dy: torch.Tensor, w_packed_t: torch.Tensor, cin: int, dx_g8: bool,
+                     dx_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Data gradient of a zero-padded bf16-mode layer inside a G8 chain (st_conv3x3_dgrad_bf16_g8): ``dy`` is fp32
+    NCHW or G8 (then ALREADY gated by the layer's ReLU); the result is G8 when ``dx_g8`` (optionally zeroed where the
+    G8 tensor ``dx_gate`` -- the layer's input activation -- is <= 0) else fp32 NCHW."""
+    lib = _lib.load()
+    dy_g8 = is_g8(dy)
+    if dy_g8:
+        n, cout, h, w = int(dy.shape[0]), int(dy.shape[1]) * 8, int(dy.shape[2]), int(dy.shape[3])
+    else:
+        assert dy.dim() == 4 and dy.dtype == torch.float32
+        n, cout, h, w = (int(v) for v in dy.shape)
+    assert conv_family(w_packed_t, cin, cout) == "bf16", "conv3x3_dgrad_g8 needs bf16-packed (transposed) weights"
+    if dx_g8:
+        dx = torch.empty((n, cin // 8, h, w, 8), dtype=torch.bfloat16, device=dy.device)
+    else:
+        dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=dy.device)
+    assert dx_gate is None or (dx_g8 and is_g8(dx_gate) and tuple(dx_gate.shape) == tuple(dx.shape)), \
+        "dx_gate must be a G8 tensor of dx's shape"
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cin, "bf16") + " dgrad", 2.0 * n * h * w * cin * cout * 9,
+                                 float(dy.numel() * dy.element_size() + dx.numel() * dx.element_size()))
+    _lib.check(lib.st_conv3x3_dgrad_bf16_g8(
+        _lib.dev_ptr(dy, "dy", dy.dtype), int(dy_g8), _lib.dev_ptr(w_packed_t, "w_packed_t", w_packed_t.dtype),
+        _lib.dev_ptr(dx, "dx", dx.dtype), int(dx_g8),
+        _lib.dev_ptr(dx_gate, "dx_gate", torch.bfloat16) if dx_gate is not None else None,
+        n, cout, h, w, cin, _lib.stream_ptr()), "st_conv3x3_dgrad_bf16_g8")
+    if ev is not None:
+        ev.record()
+    return dx
+
+
+def grad_join_g8(shape, chain: Optional[torch.Tensor] = None, chain_pooled: Optional[torch.Tensor] = None,
+                 x_gate: Optional[torch.Tensor] = None, add_post: Optional[torch.Tensor] = None,
+                 add_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """G8 bf16 of ``[x_gate > 0] * (chain + add_post) + add_pre`` for an fp32 NCHW ``shape`` (st_grad_join_g8);
+    ``chain_pooled`` instead of ``chain``: the gradient w.r.t. maxpool2x2_floor(x_gate), routed through the pool."""
+    lib = _lib.load()
+    n, c, h, w = (int(v) for v in shape)
+    ref = next(t for t in (chain, chain_pooled, x_gate, add_post, add_pre) if t is not None)
+    for name, t in (("chain", chain), ("x_gate", x_gate), ("add_post", add_post), ("add_pre", add_pre)):
+        assert t is None or tuple(t.shape) == (n, c, h, w), f"{name}: shape {tuple(t.shape)} != {(n, c, h, w)}"
+    assert chain_pooled is None or tuple(chain_pooled.shape) == (n, c, h // 2, w // 2)
+    out = torch.empty((n, c // 8, h, w, 8), dtype=torch.bfloat16, device=ref.device)
+    ptr = lambda t, name: _lib.dev_ptr(t, name) if t is not None else None      # noqa: E731
+    _lib.check(lib.st_grad_join_g8(ptr(chain, "chain"), ptr(chain_pooled, "chain_pooled"), ptr(x_gate, "x_gate"),
+                                   ptr(add_post, "add_post"), ptr(add_pre, "add_pre"),
+                                   _lib.dev_ptr(out, "out", torch.bfloat16), n, c, h, w, _lib.stream_ptr()),
+               "st_grad_join_g8")
+    return out
+
+
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tensor], want_bias: bool = True,
                   upsample2x: bool = False, pad_mode="replicate", compute: str = "f32",
                   dw_out: Optional[torch.Tensor] = None,

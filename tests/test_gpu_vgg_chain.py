@@ -1,0 +1,167 @@
+"""GPU parity of the loss VGG's differentiated pass in bf16 mode as one autograd node whose forward and backward hand
+activations / gradients over in G8 (autograd_vgg.VGGChainFunction, st_conv3x3_dgrad_bf16_g8, st_grad_join_g8).
+
+The bar is BIT-IDENTITY with the per-layer autograd graph of the fp32-activation bf16 kernels (which
+tests/test_gpu_bf16.py pins to the same-rounding oracle): a G8 value is the round-to-nearest-even the consumer's
+staging applies to an fp32 value anyway, the chunk/tap accumulation order of the data-gradient kernel is the same,
+a ReLU gate commutes with the rounding, and the join kernel adds the same fp32 terms the autograd engine adds.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from style_transfer_amd import ops as o
+    return o
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 32, 48), (1, 8, 7, 9), (3, 128, 5, 12)])
+@pytest.mark.parametrize("terms", ["chain", "chain+post", "chain+post+pre", "post", "pre", "chain+pre", "chain-nogate"])
+def test_grad_join_plain(ops, n, c, h, w, terms):
+    shape = (n, c, h, w)
+    chain = _rand(shape, 1) if "chain" in terms else None
+    post = _rand(shape, 2) if "post" in terms else None
+    pre = _rand(shape, 3) if "pre" in terms else None
+    x = None if terms in ("pre", "chain-nogate") else _rand(shape, 4)
+    got = ops.grad_join_g8(shape, chain=chain, x_gate=x, add_post=post, add_pre=pre)
+    s = torch.zeros(shape, device="cuda")
+    if chain is not None:
+        s = chain.clone()
+    if post is not None:
+        s = s + post if chain is not None else post.clone()
+    if x is not None:
+        s = torch.where(x > 0, s, torch.zeros_like(s))
+    if pre is not None:
+        s = s + pre if (chain is not None or post is not None) else pre.clone()
+    assert ops.is_g8(got)
+    assert torch.equal(got, ops.to_g8(s))
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 32, 48), (1, 16, 6, 10), (1, 128, 64, 64)])
+@pytest.mark.parametrize("terms", ["pooled", "pooled+post", "pooled+post+pre"])
+def test_grad_join_through_the_pool(ops, n, c, h, w, terms):
+    shape = (n, c, h, w)
+    x = torch.relu(_rand(shape, 5))                       # many exact ties at 0, like a ReLU output
+    x[:, :, :2, :2] = 0.0                                 # an all-zero window
+    pooled = _rand((n, c, h // 2, w // 2), 6)
+    post = _rand(shape, 7) if "post" in terms else None
+    pre = _rand(shape, 8) if "pre" in terms else None
+    got = ops.grad_join_g8(shape, chain_pooled=pooled, x_gate=x, add_post=post, add_pre=pre)
+    s = ops.maxpool2x2_bwd(x, pooled, False)              # the stand-alone kernel (tests/test_gpu_backward.py)
+    if post is not None:
+        s = s + post
+    s = torch.where(x > 0, s, torch.zeros_like(s))
+    if pre is not None:
+        s = s + pre
+    assert torch.equal(got, ops.to_g8(s))
+    # ... and torch's own routing on tie-free data
+    xr = _rand(shape, 9).requires_grad_(True)
+    torch.nn.functional.max_pool2d(xr, 2).backward(pooled)
+    got = ops.grad_join_g8(shape, chain_pooled=pooled, x_gate=xr.detach())
+    assert torch.equal(got, ops.to_g8(torch.where(xr.detach() > 0, xr.grad, torch.zeros_like(xr.grad))))
+
+
+DGRAD_CASES = [
+    # n, cout (channels of dy), cin (channels of dx), h, w
+    (2, 64, 64, 40, 40),
+    (1, 128, 64, 33, 47),
+    (1, 256, 128, 24, 40),
+    (1, 512, 512, 8, 8),
+    (3, 64, 64, 320, 320),      # persistent G8 -> G8 form (> 256 tiles)
+    (2, 64, 3, 48, 64),         # the first layer: a 3-channel fp32 gradient
+]
+
+
+@pytest.mark.parametrize("n,cout,cin,h,w", DGRAD_CASES)
+def test_dgrad_g8_is_bit_identical_to_the_gated_fp32_form(ops, n, cout, cin, h, w):
+    g = torch.Generator().manual_seed(cout + cin + h)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    wpt = ops.pack_conv3x3_weights(wt, True, "bf16")
+    dy = _rand((n, cout, h, w), 11)
+    y = torch.relu(_rand((n, cout, h, w), 12))
+    ref = ops.conv3x3_dgrad(dy, y, wpt, cin, False, ops.PAD_ZERO)            # gate applied while staging
+    dyg = ops.grad_join_g8(dy.shape, chain=dy, x_gate=y)
+    got = ops.conv3x3_dgrad_g8(dyg, wpt, cin, dx_g8=False)
+    assert torch.equal(got, ref)
+    # fp32 dy without a gate
+    assert torch.equal(ops.conv3x3_dgrad_g8(dy, wpt, cin, dx_g8=False), ops.conv3x3_dgrad(dy, None, wpt, cin, False,
+                                                                                        ops.PAD_ZERO))
+    if cin % 8 == 0:
+        below = torch.relu(_rand((n, cin, h, w), 13))
+        got8 = ops.conv3x3_dgrad_g8(dyg, wpt, cin, dx_g8=True)
+        assert torch.equal(got8, ops.to_g8(ref))
+        gated = ops.conv3x3_dgrad_g8(dyg, wpt, cin, dx_g8=True, dx_gate=ops.to_g8(below))
+        # the gate is the sign of the bf16 value the layer below handed over
+        keep = ops.from_g8(ops.to_g8(below)) > 0
+        assert torch.equal(gated, ops.to_g8(torch.where(keep, ref, torch.zeros_like(ref))))
+
+
+def _extractor(sets, seed=3):
+    import warnings
+    from style_transfer_amd.loss_network import VGG19FeatureExtractor
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = VGG19FeatureExtractor(sorted({i for s in sets for i in s}), weights=None, seed=seed).cuda()
+    return net
+
+
+@pytest.mark.parametrize("sets,n,h,w", [
+    ([[21], [2, 7, 14, 19, 25]], 2, 64, 64),          # the CLI defaults (trainer.py:446-457)
+    ([[21], [2, 7, 14, 19, 25]], 1, 72, 88),          # 9 x 11 at the third pool: the odd-size route
+    ([[4, 8], [1, 6, 11]], 2, 32, 48),                # captured pool output, captured ReLU indices, pre-ReLU 11
+    ([[25], [21, 25]], 1, 32, 32),                    # one conv captured both before and after its ReLU
+    ([[7]], 1, 40, 24),                               # a single tap; nothing captured below it
+])
+def test_chain_matches_the_per_layer_graph(sets, n, h, w):
+    from style_transfer_amd import precision
+    net = _extractor(sets)
+    x0 = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(5)).cuda()
+    weights = [torch.randn(1, generator=torch.Generator().manual_seed(40 + k)).item() for k in range(16)]
+
+    def run(chain):
+        net.GRAD_CHAIN = chain
+        x = x0.clone().requires_grad_(True)
+        with precision.compute_dtype("bf16"):
+            outs = net.forward_multi(x, sets)
+            flat = [t for s in outs for t in s]
+            loss = sum(wt * (t * t).mean() + 0.1 * wt * t.mean() for wt, t in zip(weights, flat))
+            loss.backward()
+        return [t.detach() for t in flat], x.grad
+
+    try:
+        ref_out, ref_grad = run(False)
+        got_out, got_grad = run(True)
+    finally:
+        net.GRAD_CHAIN = True
+    for a, b in zip(got_out, ref_out):
+        assert torch.equal(a, b)
+    assert float(ref_grad.abs().max()) > 0
+    assert torch.equal(got_grad, ref_grad)
+
+
+def test_chain_with_a_tap_that_carries_no_gradient():
+    from style_transfer_amd import precision
+    sets = [[21], [2, 7, 14]]
+    net = _extractor(sets)
+    x0 = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(6)).cuda()
+
+    def run(chain):
+        net.GRAD_CHAIN = chain
+        x = x0.clone().requires_grad_(True)
+        with precision.compute_dtype("bf16"):
+            outs = net.forward_multi(x, sets)
+            (outs[1][1] ** 2).mean().backward()           # only relu2_2: the layers above it see no gradient
+        return x.grad
+    try:
+        ref, got = run(False), run(True)
+    finally:
+        net.GRAD_CHAIN = True
+    assert torch.equal(got, ref)
