@@ -626,6 +626,18 @@ def main():
 
     ctx = Ctx()
     line = {}
+
+    def extra(fn, *a, **kw):
+        # Secondary legs under a launcher (N > 1): a failure is recorded in the line instead of taking the headline
+        # (the inference and fp32 training legs above them) down with it.  N = 1: errors surface as usual.
+        if ctx.world == 1:
+            return fn(*a, **kw)
+        try:
+            return fn(*a, **kw)
+        except Exception as e:      # noqa: BLE001
+            torch.cuda.synchronize()
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if args.mode in ("both", "infer"):
         line = run_inference(ctx, args, compute=args.compute)
     if args.mode in ("both", "train"):
@@ -635,7 +647,7 @@ def main():
             g = run_train(ctx, args, use_vincent=False, compute=args.compute, hip_graph=True)
             train["hip_graph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "launch")}
         if not args.no_gram:
-            train["gram"] = run_train(ctx, args, use_vincent=True, compute=args.compute)
+            train["gram"] = extra(run_train, ctx, args, use_vincent=True, compute=args.compute)
         if args.mode == "train":
             line = dict(train, higher_is_better=True, vs_baseline=None, data="synthetic")
             train = None
@@ -645,19 +657,21 @@ def main():
         # BASELINE configs[3] per-GPU shape (batch 64 over 8 GPUs = 8 per GPU at 512x512, bf16 compute)
         bf = {}
         if args.mode in ("both", "infer"):
-            bf["inference"] = run_inference(ctx, args, compute="bf16")
+            bf["inference"] = extra(run_inference, ctx, args, compute="bf16")
         if args.mode in ("both", "train"):
-            bf["train"] = run_train(ctx, args, use_vincent=False, compute="bf16", batch=8, side=512)
-            bf["train"]["config"]["workload"] = "BASELINE configs[3] per-GPU shape: " + bf["train"]["config"]["workload"]
+            bf["train"] = extra(run_train, ctx, args, use_vincent=False, compute="bf16", batch=8, side=512)
+            if "config" in bf["train"]:
+                bf["train"]["config"]["workload"] = ("BASELINE configs[3] per-GPU shape: " +
+                                                     bf["train"]["config"]["workload"])
         line["bf16"] = bf
         # fp32-grade results from the bf16 matrix pipe (hi+lo operand split, 3 MFMAs per product); same shapes as
         # the headline legs (configs[1] inference, configs[2] training; weight gradient on the exact fp32 kernel)
         x3 = {}
         if args.mode in ("both", "infer"):
-            x3["inference"] = run_inference(ctx, args, compute="bf16x3")
+            x3["inference"] = extra(run_inference, ctx, args, compute="bf16x3")
         if args.mode in ("both", "train"):
-            x3["train"] = run_train(ctx, args, use_vincent=False, compute="bf16x3",
-                                    hip_graph=(ctx.world == 1 and not args.no_hip_graph))
+            x3["train"] = extra(run_train, ctx, args, use_vincent=False, compute="bf16x3",
+                                hip_graph=(ctx.world == 1 and not args.no_hip_graph))
         line["bf16x3"] = x3
     if ctx.world > 1 and args.mode in ("both", "train") and not args.no_hip_graph:
         # Data-parallel step replayed from three HIP graphs around the two eager all-reduces.  Last leg of the run and

@@ -225,6 +225,11 @@ int st_relu_bwd(const float* y, const float* dy, float* dx, long long n, st_stre
 int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, int ceil_mode,
                       st_stream_t stream);
 
+/* floor-mode pool of fp32 NCHW [n][c][h][w] written in G8 bf16 [n][c/8][h/2][w/2][8] (the input form of the next
+ * conv of a bf16-mode chain, st_conv3x3_fwd_bf16_g8); c % 8 == 0, h and w even (floor == ceil).  Same bits as
+ * st_maxpool2x2_fwd followed by the bf16 rounding of that conv's staging. */
+int st_maxpool2x2_fwd_g8(const float* x, void* y_g8, int n, int c, int h, int w, st_stream_t stream);
+
 /* backward: x is the pool INPUT [nc][h][w], dy [nc][ho][wo]; dx [nc][h][w] fully overwritten.
  * Ties go to the first maximum in scan order, as torch.max_pool2d does. */
 int st_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,

@@ -74,8 +74,11 @@ class VGGChainFunction(torch.autograd.Function):
         for k, u in enumerate(units):
             if u[0] == "pool":
                 idx = u[1]
-                h, w = int(cur.shape[2]), int(cur.shape[3])
-                cur = ops.maxpool2x2(cur, False)
+                c, h, w = int(cur.shape[1]), int(cur.shape[2]), int(cur.shape[3])
+                if idx not in post and k + 1 < len(units) and h % 2 == 0 and w % 2 == 0 and c % 16 == 0:
+                    cur = ops.maxpool2x2_g8(cur)         # nobody captures it: straight into the next conv's input form
+                else:
+                    cur = ops.maxpool2x2(cur, False)
                 if idx in post:
                     outs[("post", idx)] = cur
                 meta.append({"kind": "pool", "idx": idx, "h": h, "w": w})

@@ -148,6 +148,34 @@ __global__ __launch_bounds__(256) void grad_join_pool_kernel(JoinParams p) {
   }
 }
 
+// Floor-mode 2x2 max pool of an fp32 NCHW tensor written straight in G8 (torchvision vgg19 'M' between a captured
+// layer and the next conv of a G8 chain): rounding is monotonic, so round(max) == max(round) -- the same bits the
+// next conv's staging would make of the fp32 pool output.  item = (image, channel group, output pixel); h, w even.
+__global__ __launch_bounds__(256) void maxpool2x2_g8_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int c,
+                                                           int h, int w, long long total) {
+  const int ho = h >> 1, wo = w >> 1;
+  const long long hw = (long long)h * w;
+  const int cgs = c >> 3;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ox = int(e % wo);
+    long long t = e / wo;
+    const int oy = int(t % ho);
+    t /= ho;
+    const int cg = int(t % cgs);
+    const long long b = t / cgs;
+    const float* src = x + (b * c + cg * 8) * hw + (long long)(2 * oy) * w + 2 * ox;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x2 r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(src + j * hw));
+      const f32x2 r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(src + j * hw + w));
+      v[j] = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r1[0], r1[1]));
+    }
+    y[e] = pack8(v);
+  }
+}
+
 inline int grid_for(long long total) {
   return (int)std::max<long long>(1, std::min<long long>(st::cdivll(total, 256), 256 * 16));
 }
@@ -187,4 +215,16 @@ extern "C" int st_grad_join_g8(const float* chain, const float* chain_pooled, co
     hipLaunchKernelGGL(grad_join_kernel<1>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
   }
   return st::check_launch("st_grad_join_g8");
+}
+
+extern "C" int st_maxpool2x2_fwd_g8(const float* x, void* y_g8, int n, int c, int h, int w, st_stream_t stream) {
+  ST_REQUIRE(x && y_g8, "st_maxpool2x2_fwd_g8: null pointer");
+  ST_REQUIRE(n > 0 && c > 0 && c % 8 == 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0,
+             "st_maxpool2x2_fwd_g8: bad dims n=%d c=%d h=%d w=%d (c %% 8 == 0, even h and w)", n, c, h, w);
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(x) % 8 == 0 && reinterpret_cast<uintptr_t>(y_g8) % 16 == 0,
+             "st_maxpool2x2_fwd_g8: x must be 8-byte and y_g8 16-byte aligned");
+  const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2);
+  hipLaunchKernelGGL(maxpool2x2_g8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x,
+                     (u32x4*)y_g8, c, h, w, total);
+  return st::check_launch("st_maxpool2x2_fwd_g8");
 }

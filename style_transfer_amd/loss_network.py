@@ -216,8 +216,13 @@ class VGG19FeatureExtractor(nn.Module):
         while idx <= last_all:
             kind, cin, cout = self.layout[idx]
             if kind != "conv":
-                x = ops.maxpool2x2(x, False)
-                post[idx] = x
+                c_, h_, w_ = (int(v) for v in x.shape[1:])
+                if (compute == "bf16" and idx not in want and idx + 1 <= last_all and h_ % 2 == 0 and w_ % 2 == 0
+                        and c_ % 16 == 0):
+                    x = ops.maxpool2x2_g8(x)               # uncaptured: straight into the next conv's input form
+                else:
+                    x = ops.maxpool2x2(x, False)
+                    post[idx] = x
                 idx += 1
                 continue
             conv = self.convs[str(idx)]

@@ -430,6 +430,16 @@ def maxpool2x2(x: torch.Tensor, ceil_mode: bool) -> torch.Tensor:
     return y
 
 
+def maxpool2x2_g8(x: torch.Tensor) -> torch.Tensor:
+    """Floor-mode 2x2 max pool of fp32 NCHW written in G8 (st_maxpool2x2_fwd_g8); c % 8 == 0, even h and w."""
+    lib = _lib.load()
+    n, c, h, w = (int(v) for v in x.shape)
+    y = torch.empty((n, c // 8, h // 2, w // 2, 8), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.st_maxpool2x2_fwd_g8(_lib.dev_ptr(x, "x"), _lib.dev_ptr(y, "y", torch.bfloat16), n, c, h, w,
+                                        _lib.stream_ptr()), "st_maxpool2x2_fwd_g8")
+    return y
+
+
 def adain(content: torch.Tensor, style: torch.Tensor, eps_content: float, eps_style: float,
           alpha: float = 1.0, save_stats: bool = False,
           eps_dev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:

@@ -165,3 +165,28 @@ def test_chain_with_a_tap_that_carries_no_gradient():
     finally:
         net.GRAD_CHAIN = True
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 32, 48), (1, 16, 2, 2), (3, 128, 70, 36)])
+def test_maxpool_to_g8(ops, n, c, h, w):
+    x = _rand((n, c, h, w), 21)
+    assert torch.equal(ops.maxpool2x2_g8(x), ops.to_g8(ops.maxpool2x2(x, False)))
+
+
+def test_no_grad_g8_pass_with_the_pool_written_in_g8():
+    """loss_network._forward_multi_g8 (style / content originals): captured layer -> pool -> conv, the pool output
+    goes to the next conv in G8; same bits as the per-layer fp32-activation pass."""
+    from style_transfer_amd import precision
+    sets = [[21], [2, 7, 14, 19, 25]]
+    net = _extractor(sets)
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(8)).cuda()
+    with precision.compute_dtype("bf16"), torch.no_grad():
+        got = net.forward_multi(x, sets)
+    net.GRAD_CHAIN = False
+    try:
+        with precision.compute_dtype("bf16"):
+            ref = net.forward_multi(x.clone().requires_grad_(True), sets)      # per-layer graph, fp32 activations
+    finally:
+        net.GRAD_CHAIN = True
+    for a, b in zip([t for s in got for t in s], [t for s in ref for t in s]):
+        assert torch.equal(a, b.detach())
