@@ -143,6 +143,29 @@ int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const 
  * rounding is the one the next launch's staging applies to an fp32 gradient). */
 int st_conv3x3_dgrad_bf16_g8(const void* dy, int dy_g8, const void* w_packed_t, void* dx, int dx_g8,
                              const void* dx_gate_g8, int n, int cout, int h, int w, int cin, st_stream_t stream);
+/* bf16 mode, data gradient of a REPLICATE-padded decoder layer (generator.py:85-130; loss.backward() of
+ * trainer.py:472) inside a G8 chain.  dy [n][cout][h][w]: fp32 NCHW or (dy_g8) G8, already gated.  The padded-domain
+ * result goes to `workspace` (st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, ST_PAD_REPLICATE)) and is folded onto the
+ * source pixels [n][cin][h >> up][w >> up] (adjoint of the pad and of the nearest x2 upsample), zeroed where dx_gate
+ * -- the layer's input activation, fp32 NCHW or (dx_gate_g8) G8, may be NULL -- is <= 0, and written in every form
+ * requested (each may be NULL): dx_f32 fp32 NCHW; dx_g8 G8 (operand of the next st_conv3x3_dgrad_bf16_g8_chain);
+ * dx_g16 bf16 [n][cin][h][w] and bias_slabs [n * st_conv3x3_dgrad_fold8_bias_slabs(h, w, up)][cin] fp32 partial
+ * sums (operands of st_conv3x3_wgrad_bf16_pre of the layer below).  Needs cin % 8 == 0 and (w >> up) % 4 == 0.
+ * Same fp32 values as st_conv3x3_dgrad_bf16 with dx_gate. */
+int st_conv3x3_dgrad_bf16_g8_chain(const void* dy, int dy_g8, const void* w_packed_t, float* workspace,
+                                   const void* dx_gate, int dx_gate_g8, float* dx_f32, void* dx_g8, void* dx_g16,
+                                   float* bias_slabs, int n, int cout, int h, int w, int cin, int upsample2x,
+                                   st_stream_t stream);
+int st_conv3x3_dgrad_fold8_bias_slabs(int h, int w, int upsample2x);
+/* Weight gradient of a decoder layer whose gated output gradient arrives READY from the launch above: g16 bf16
+ * [n][cout][H][W] and bias_slabs [n_bias_slabs][cout] (summed in a fixed order into dbias; dbias may be NULL); x is
+ * the layer input, fp32 NCHW or (x_g8) G8 [n][cin/8][hin][win][8].  Same GEMM as st_conv3x3_wgrad_bf16's staged form
+ * (needs W % 32 == 0, H % 4 == 0, cout != 3 where H, W = the conv-input dims after the upsample; the workspace size
+ * is 0 for other shapes: use st_conv3x3_wgrad_bf16 there). */
+size_t st_conv3x3_wgrad_bf16_pre_workspace_bytes(int n, int cout, int cin, int h, int w);
+int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g16, const float* bias_slabs, int n_bias_slabs,
+                              float* dw, float* dbias, float* workspace, int n, int cin, int hin, int win, int cout,
+                              int upsample2x, int pad_mode, st_stream_t stream);
 /* The gradient that reaches a CAPTURED layer output (a loss tap of trainer.py:446-457, fp32 NCHW) or the input of
  * a max pool, formed in one pass as the G8 operand of that layer's st_conv3x3_dgrad_bf16_g8:
  *     out_g8 = [x_gate > 0] * (chain + add_post) + add_pre

@@ -32,6 +32,12 @@ SIGNATURES = {
                                          c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_dgrad_bf16_g8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p]),
+    "st_conv3x3_dgrad_bf16_g8_chain": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_dgrad_fold8_bias_slabs": (c_int, [c_int, c_int, c_int]),
+    "st_conv3x3_wgrad_bf16_pre_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "st_conv3x3_wgrad_bf16_pre": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "st_grad_join_g8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p]),
     "st_conv3x3_dgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

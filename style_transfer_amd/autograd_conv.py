@@ -117,3 +117,87 @@ class DecoderChainFunction(torch.autograd.Function):
                 if i == 0:
                     dx = g
         return (dx, None, None, *grads)
+
+
+class DecoderChainG8Function(torch.autograd.Function):
+    """DecoderChainFunction for the bf16 compute mode with G8 hand-overs in BOTH directions.
+
+    Forward: generator._g8_chain's launches (fp32 in, G8 between the layers, bit-identical to the fp32-activation
+    kernels); the last ReLU layer writes fp32 because the 3-channel top layer's vector-ALU gradient kernels read
+    fp32.  The saved layer inputs are the G8 tensors: half the bytes, and already the bf16 values the weight
+    gradient rounds its input to.
+
+    Backward, per layer from the top: ONE data-gradient call (ops.conv3x3_dgrad_g8_chain) takes the gated gradient
+    in G8 (staged by LDS-DMA), folds the padded-domain result, applies the ReLU gate of the layer below from its G8
+    activation and writes the gradient in the two bf16 forms its consumers take -- G8 for the next data-gradient
+    launch, pixel-major bf16 plus bias partial sums for the next weight-gradient GEMM (ops.conv3x3_wgrad_pre): no
+    fp32 gradient tensor between the layers, no weight-gradient prep pass over dy.  Same fp32 values per element
+    as DecoderChainFunction before the (identical) bf16 roundings; the bias gradient is summed in another (fixed)
+    order.  Shapes outside the staged weight-gradient form use DecoderChainFunction (Decoder.forward decides).
+    """
+
+    @staticmethod
+    def usable(x, specs, params) -> bool:
+        n, c, h, w = (int(v) for v in x.shape)
+        for i, (key, cout, up, relu) in enumerate(specs):
+            cin = int(params[2 * i].shape[1])
+            if up:
+                h, w = 2 * h, 2 * w
+            if cin % 16 or w % 32 or h % 4:
+                return False
+            if cout != 3 and (cout % 8 or not ops.wgrad_pre_ok(n, cout, cin, h, w)):
+                return False
+        return int(specs[-1][1]) == 3 and not specs[-1][3] and all(sp[3] for sp in specs[:-1])
+
+    @staticmethod
+    def forward(ctx, x, cache, specs, *params):
+        n_l = len(specs)
+        acts = [x]
+        for i, (key, cout, up, relu) in enumerate(specs):
+            w, b = params[2 * i], params[2 * i + 1]
+            wp = cache.get(key, w, False, "bf16")
+            acts.append(ops.conv3x3_g8(acts[-1], wp, b.detach(), cout, upsample2x=up, pad_mode=ops.PAD_REPLICATE,
+                                       relu=relu, pool=False, y_g8=i < n_l - 2))
+        ctx.cache, ctx.specs = cache, specs
+        ctx.save_for_backward(*acts[:-1], *params)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.specs)
+        saved = ctx.saved_tensors
+        acts, params = saved[:n], saved[n:]
+        g = g.contiguous()
+        grads = [None] * (2 * n)
+        g16 = bias = None              # the bf16 operand forms of the gradient w.r.t. layer i's output (i < n - 1)
+        dx = None
+        for i in range(n - 1, -1, -1):
+            key, cout, up, relu = ctx.specs[i]
+            w, b = params[2 * i], params[2 * i + 1]
+            x_i = acts[i]
+            need_w, need_b = ctx.needs_input_grad[3 + 2 * i], ctx.needs_input_grad[4 + 2 * i]
+            if need_w or need_b:
+                direct = (getattr(ctx.cache, "direct_grads", False) and need_w and need_b and w.grad is not None
+                          and b.grad is not None and w.grad.is_contiguous() and b.grad.is_contiguous())
+                if i == n - 1:         # 64 -> 3: fp32 dy, fp32 x, the vector-ALU kernel
+                    dw, db = ops.conv3x3_wgrad(x_i, g, None, want_bias=True, upsample2x=up,
+                                               pad_mode=ops.PAD_REPLICATE, compute="bf16",
+                                               dw_out=w.grad if direct else None, db_out=b.grad if direct else None)
+                else:
+                    dw, db = ops.conv3x3_wgrad_pre(x_i, g16, bias, up, ops.PAD_REPLICATE,
+                                                   dw_out=w.grad if direct else None,
+                                                   db_out=b.grad if direct else None)
+                if not direct:
+                    grads[2 * i] = dw if need_w else None
+                    grads[2 * i + 1] = db if need_b else None
+            if i > 0 or ctx.needs_input_grad[0]:
+                wpt = ctx.cache.get(key, w, True, "bf16")
+                gate = x_i if i > 0 else None                   # every layer below the top one ends in a ReLU
+                below_trains = i > 0 and (ctx.needs_input_grad[1 + 2 * i] or ctx.needs_input_grad[2 + 2 * i])
+                dxf, g8, g16, bias = ops.conv3x3_dgrad_g8_chain(
+                    g, wpt, int(w.shape[1]), up, gate, want_f32=i == 0, want_g8=i > 0, want_g16=below_trains,
+                    want_bias=below_trains)
+                g = g8
+                if i == 0:
+                    dx = dxf
+        return (dx, None, None, *grads)

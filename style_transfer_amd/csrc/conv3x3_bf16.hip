@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       idx -= part * C::NITEM;                                                              \
       const int half = idx / C::PLANE, pidx = idx - half * C::PLANE;                       \
       const int r = pidx / HC, cc = pidx - r * HC;                                         \
-      const int gy = (y0_) + r - 1, gx = (x0_) + cc - 1;                                   \
+      const int gy = (y0_) + r - 1 - p.shift, gx = (x0_) + cc - 1 - p.shift;               \
       if (p.pad_zero && i * 8 + wave < C::NXI && (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W)) \
         xoob_ |= 1u << i;                                                                  \
       int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);                    \
@@ -876,6 +876,10 @@ namespace st {
 // csrc/conv3x3.hip: adjoint of the replicate pad (+ upsample) on the padded data gradient
 int launch_dgrad_fold(const float* dxp, float* dx, const float* gate, int n, int cin, int h, int w, int up,
                       hipStream_t s);
+// csrc/dgrad_fold8.hip: the same, eight channels per item, with the G8 / G16 / bias-sum outputs of the G8 chain
+int fold8_blocks_per_plane(int hs, int ws, int* iters_out);
+int launch_dgrad_fold8(const float* dxp, const float* gate_f32, const void* gate_g8, float* dx, void* g8, void* g16,
+                       float* bias, int n, int c, int h, int w, int up, hipStream_t s);
 }  // namespace st
 
 extern "C" size_t st_conv3x3_packed_elems_bf16(int cout, int cin) {
@@ -1015,6 +1019,55 @@ extern "C" int st_conv3x3_dgrad_bf16_g8(const void* dy, int dy_g8, const void* w
   ST_REQUIRE(!dx_gate_g8 || dx_g8, "st_conv3x3_dgrad_bf16_g8: dx_gate_g8 needs a G8 dx");
   return conv3x3_fwd_g8_impl(dy, dy_g8, w_packed_t, nullptr, dx, dx_g8, n, cout, h, w, cin, 0, ST_PAD_ZERO, 0, 0,
                              stream, false, dx_gate_g8);
+}
+
+// Data gradient of a REPLICATE-padded (decoder) layer inside a G8 chain: dy fp32 NCHW or G8 (already gated), the
+// padded-domain result goes to `workspace` (st_conv3x3_dgrad_workspace_bytes) and st::launch_dgrad_fold8 folds it,
+// applies the gate of the layer below and writes the requested forms (see include/st_hip.h).
+extern "C" int st_conv3x3_dgrad_bf16_g8_chain(const void* dy, int dy_g8, const void* w_packed_t, float* workspace,
+                                              const void* dx_gate, int dx_gate_g8, float* dx_f32, void* dx_g8,
+                                              void* dx_g16, float* bias_slabs, int n, int cout, int h, int w, int cin,
+                                              int upsample2x, st_stream_t stream) {
+  ST_REQUIRE(dy && w_packed_t && workspace, "st_conv3x3_dgrad_bf16_g8_chain: null pointer");
+  ST_REQUIRE(dx_f32 || dx_g8 || dx_g16, "st_conv3x3_dgrad_bf16_g8_chain: no output requested");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0,
+             "st_conv3x3_dgrad_bf16_g8_chain: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
+  ST_REQUIRE(!upsample2x || (h % 2 == 0 && w % 2 == 0),
+             "st_conv3x3_dgrad_bf16_g8_chain: upsampled layer needs even h, w (got %dx%d)", h, w);
+  ST_REQUIRE(cin % 8 == 0 && (w >> (upsample2x ? 1 : 0)) % 4 == 0,
+             "st_conv3x3_dgrad_bf16_g8_chain: needs cin %% 8 == 0 and a source width that is a multiple of 4");
+  ST_REQUIRE(!dy_g8 || (cout % KC == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0),
+             "st_conv3x3_dgrad_bf16_g8_chain: a G8 dy needs cout %% 16 == 0 and 16-byte alignment");
+  for (const void* q : {(const void*)workspace, dx_gate, (const void*)dx_f32, (const void*)dx_g8, (const void*)dx_g16})
+    ST_REQUIRE(reinterpret_cast<uintptr_t>(q) % 16 == 0, "st_conv3x3_dgrad_bf16_g8_chain: 16-byte aligned buffers expected");
+  ST_REQUIRE((long long)(h + 2) * (w + 2) * 16 < (1LL << 31), "st_conv3x3_dgrad_bf16_g8_chain: plane too large");
+  hipStream_t s = (hipStream_t)stream;
+  ConvParams p;
+  p.x = (const float*)dy; p.gate = nullptr; p.wp = (const u32x4*)w_packed_t; p.bias = nullptr; p.y = workspace;
+  p.n = n; p.cin = cout; p.hs = h; p.ws = w; p.cout = cin;
+  p.up = 0; p.H = h; p.W = w;
+  p.Ho = h + 2; p.Wo = w + 2; p.shift = 1;
+  p.ldo = st::padded_row(w); p.pool = 0;
+  p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
+  p.nchunks = st::cdiv(cout, KC);
+  p.pad_zero = 1; p.relu = 0;
+  int rc;
+  if (dy_g8) {
+    if (cin > 64) rc = launch_conv_g8<2, 4, 2, 4>(p, true, false, s);
+    else if (cin > 32) rc = launch_conv_g8<2, 4, 1, 8>(p, true, false, s);
+    else rc = launch_conv_g8<1, 4, 1, 8>(p, true, false, s);
+  } else {
+    rc = dispatch_conv<false>(p, s, false);
+  }
+  if (rc != ST_OK) return rc;
+  return st::launch_dgrad_fold8(workspace, dx_gate_g8 ? nullptr : (const float*)dx_gate, dx_gate_g8 ? dx_gate : nullptr,
+                                dx_f32, dx_g8, dx_g16, bias_slabs, n, cin, h, w, upsample2x ? 1 : 0, s);
+}
+
+extern "C" int st_conv3x3_dgrad_fold8_bias_slabs(int h, int w, int upsample2x) {
+  const int up = upsample2x ? 1 : 0;
+  if (h <= 0 || w <= 0 || (w >> up) % 4 != 0) return 0;
+  return st::fold8_blocks_per_plane(h >> up, w >> up, nullptr);
 }
 
 extern "C" int st_conv3x3_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y,

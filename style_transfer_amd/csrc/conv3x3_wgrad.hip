@@ -255,6 +255,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// Many short slabs (the bias partial sums of the G8 decoder chain: hundreds of [cout] rows): one wave per output
+// element, lanes stride over the slabs, fixed-order shuffle tree -- slab_reduce_kernel would walk them serially.
+__global__ __launch_bounds__(64) void slab_reduce_wave_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                             int n, int nslabs) {
+  const int e = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nslabs; k += 64) s += slabs[(size_t)k * n + e];
+  s = st::wave_sum(s);
+  if (threadIdx.x == 0) out[e] = s;
+}
+
 // ================================================================================================
 // bf16 compute mode (BASELINE configs[3]): the same GEMM with bf16 operands and fp32 accumulation,
 // v_mfma_f32_32x32x16_bf16, K step = 16 consecutive pixels of one tile row.
@@ -552,6 +563,54 @@ __global__ __launch_bounds__(256) void wgrad_prep_x_kernel(const float* __restri
       if (g == 0) pk[7] = (__bf16)e; else pk[0] = (__bf16)e;
     }
     *reinterpret_cast<u32x4*>(x16 + plane * size_t(H + 2) * wp + size_t(py) * wp + g * 8) = __builtin_bit_cast(u32x4, pk);
+  }
+}
+
+// The same image from a G8 activation (bf16 [n][c/8][hs][ws][8], what the layers of a bf16-mode chain hand each
+// other): one item = 8 channels x 8 consecutive columns of one padded row -- 8 (4 under the upsample) 16-B pixel
+// reads, an 8 x 8 transpose in registers, one 16-B store per channel.  No rounding: the values already are bf16 (the
+// round-to-nearest-even wgrad_prep_x_kernel would apply to the fp32 form of the same activation).
+__global__ __launch_bounds__(256) void wgrad_prep_x_g8_kernel(const u32x4* __restrict__ xg,
+                                                             unsigned short* __restrict__ x16, long long groups_total,
+                                                             int cgs, int hs, int ws, int H, int W, int wp, int up,
+                                                             int pad_zero) {
+  const int groups = wp / 8;
+  const long long per_cg = (long long)(H + 2) * groups, total = groups_total * per_cg;
+  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += gridDim.x * 256LL) {
+    const long long bcg = idx / per_cg;                  // image * cgs + channel group
+    const int rem = int(idx - bcg * per_cg);
+    const int py = rem / groups, g = rem - py * groups;
+    const int gy = py - 1;
+    const bool rowin = gy >= 0 && gy < H;
+    int cy = min(max(gy, 0), H - 1);
+    if (up) cy >>= 1;
+    const u32x4* row = xg + (bcg * hs + cy) * (long long)ws;
+    const bool keep = rowin || !pad_zero;
+    u32x4 px[8];                                         // px[k] = the 8 channels of column k of this item
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    if (g >= 1 && g < groups - 1) {
+      const int gx0 = (g - 1) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) px[k] = keep ? row[up ? ((gx0 + k) >> 1) : (gx0 + k)] : zero;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) px[k] = zero;
+      const u32x4 e = (keep && !pad_zero) ? row[g == 0 ? 0 : ((W - 1) >> up)] : zero;
+      if (g == 0) px[7] = e; else px[0] = e;
+    }
+    const long long cg = bcg % cgs, b = bcg / cgs;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                        // channel j of the group: one halfword of every pixel
+      u32x4 o;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        const unsigned lo = (j & 1) ? (px[2 * k2][j >> 1] >> 16) : (px[2 * k2][j >> 1] & 0xffffu);
+        const unsigned hi = (j & 1) ? (px[2 * k2 + 1][j >> 1] >> 16) : (px[2 * k2 + 1][j >> 1] & 0xffffu);
+        o[k2] = lo | (hi << 16);
+      }
+      const long long plane = (b * cgs + cg) * 8 + j;
+      *reinterpret_cast<u32x4*>(x16 + plane * size_t(H + 2) * wp + size_t(py) * wp + g * 8) = o;
+    }
   }
 }
 
@@ -928,4 +987,76 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(st::cdiv(cout, 256)), dim3(256), 0, s,
                        p.bias_slabs, dbias, (long long)cout, pl.nsplit);
   return st::check_launch("st_conv3x3_wgrad_bf16(reduce)");
+}
+
+// Weight gradient inside the bf16 mode's G8 decoder chain: operand G arrives READY (bf16 [n][cout][H][W], written by
+// st_conv3x3_dgrad_bf16_g8_chain of the layer above together with the bias partial sums), x is fp32 NCHW or G8.
+// Staged shapes only (W % 32 == 0, H % 4 == 0, cout != 3).
+extern "C" size_t st_conv3x3_wgrad_bf16_pre_workspace_bytes(int n, int cout, int cin, int h, int w) {
+  size_t bytes = align16(st_conv3x3_wgrad_workspace_bytes(n, cout, cin, h, w));
+  if (bytes == 0 || !wgrad_bf16_staged_ok(cout, h, w)) return 0;
+  bytes += align16(size_t(n) * cin * (h + 2) * (w + 2 * bf::XPAD) * sizeof(unsigned short));   // Xp
+  return bytes;
+}
+
+extern "C" int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g16, const float* bias_slabs,
+                                         int n_bias_slabs, float* dw, float* dbias, float* workspace, int n, int cin,
+                                         int hin, int win, int cout, int upsample2x, int pad_mode,
+                                         st_stream_t stream) {
+  ST_REQUIRE(x && g16 && dw && workspace, "st_conv3x3_wgrad_bf16_pre: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
+             "st_conv3x3_wgrad_bf16_pre: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO, "st_conv3x3_wgrad_bf16_pre: bad pad_mode %d",
+             pad_mode);
+  ST_REQUIRE(!dbias || (bias_slabs && n_bias_slabs > 0), "st_conv3x3_wgrad_bf16_pre: dbias needs the bias partial sums");
+  const int up = upsample2x ? 1 : 0;
+  const int H = hin << up, W = win << up;
+  ST_REQUIRE(wgrad_bf16_staged_ok(cout, H, W), "st_conv3x3_wgrad_bf16_pre: needs W %% 32 == 0, H %% 4 == 0, cout != 3 "
+             "(got %dx%d, cout=%d)", H, W, cout);
+  ST_REQUIRE(!x_g8 || cin % 8 == 0, "st_conv3x3_wgrad_bf16_pre: a G8 x needs cin %% 8 == 0");
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(g16) % 16 == 0 &&
+             reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "st_conv3x3_wgrad_bf16_pre: 16-byte aligned buffers expected");
+  ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, bf::TRB) <= 0x7fffffffLL && (long long)n * cin <= 0x7fffffffLL,
+             "st_conv3x3_wgrad_bf16_pre: too many pixel tiles");
+  int sbo, sci;
+  wgrad_shape(cout, &sbo, &sci);
+  const Plan pl = make_plan(n, cout, cin, H, W, bf::TRB, sbo, sci);
+  WgradParams p;
+  p.dy = nullptr; p.ygate = nullptr; p.x = nullptr;
+  p.slabs = workspace;
+  p.bias_slabs = nullptr;
+  p.n = n; p.cout = cout; p.cin = cin; p.hs = hin; p.ws = win; p.H = H; p.W = W;
+  p.up = up; p.pad_zero = pad_mode == ST_PAD_ZERO;
+  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
+  p.tiles_per_split = pl.tiles_per_split; p.nsplit = pl.nsplit;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(st::cdiv(cin, sci), st::cdiv(cout, sbo), pl.nsplit);
+  unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+  unsigned short* x16 = reinterpret_cast<unsigned short*>(wsb + align16(st_conv3x3_wgrad_workspace_bytes(n, cout, cin, H, W)));
+  const int wp = W + 2 * bf::XPAD;
+  if (x_g8) {
+    const long long bcgs = (long long)n * (cin / 8);
+    const long long items = bcgs * (H + 2) * (wp / 8);
+    hipLaunchKernelGGL(bf::wgrad_prep_x_g8_kernel, dim3((unsigned)std::min<long long>(st::cdivll(items, 256), 16384)),
+                       dim3(256), 0, s, (const bf::u32x4*)x, x16, bcgs, cin / 8, hin, win, H, W, wp, up, p.pad_zero);
+  } else {
+    const long long items = (long long)n * cin * (H + 2) * (wp / 8);
+    hipLaunchKernelGGL(bf::wgrad_prep_x_kernel, dim3((unsigned)std::min<long long>(st::cdivll(items, 256), 16384)),
+                       dim3(256), 0, s, (const float*)x, x16, (long long)n * cin, hin, win, H, W, wp, up, p.pad_zero);
+  }
+  p.g16 = (unsigned short*)g16; p.x16 = x16; p.wp = wp;
+  if (sbo == 64)
+    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), grid, dim3(NTHREADS),
+                      (bf::SShape<64, 64>::LDS), s, p);
+  else
+    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<128, 32>), grid, dim3(NTHREADS),
+                      (bf::SShape<128, 32>::LDS), s, p);
+  int rc = st::check_launch("st_conv3x3_wgrad_bf16_pre");
+  if (rc != ST_OK) return rc;
+  const long long nw = (long long)cout * cin * 9;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(nw, 256), 2048)), dim3(256), 0, s,
+                     p.slabs, dw, nw, pl.nsplit);
+  if (dbias)
+    hipLaunchKernelGGL(slab_reduce_wave_kernel, dim3(cout), dim3(64), 0, s, bias_slabs, dbias, cout, n_bias_slabs);
+  return st::check_launch("st_conv3x3_wgrad_bf16_pre(reduce)");
 }

@@ -10,6 +10,7 @@ upsample) is ONE fused MFMA implicit-GEMM launch.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple, Union
 
 import torch
@@ -167,6 +168,9 @@ class Decoder(nn.Module):
 
     CONV3 = (1, 5, 8, 11, 14, 18, 21, 25, 28)
     UP_AFTER = (1, 14, 21)
+    #: bf16 mode, training: G8 hand-overs in both directions (autograd_conv.DecoderChainG8Function); ST_DEC_CHAIN=0:
+    #: the fp32-activation chain
+    G8_CHAIN = os.environ.get("ST_DEC_CHAIN", "1") != "0"
 
     def __init__(self, use_pretrained_WCT: bool = False, do_train: bool = False,
                  weights: Union[str, dict, None] = None):
@@ -206,6 +210,10 @@ class Decoder(nn.Module):
                 specs.append((idx, int(seq[idx].weight.shape[0]), up, idx != 28))
                 up = idx in self.UP_AFTER
             assert not specs[-1][3], "the chain backward relies on the last conv having no ReLU"
+            if precision.get_compute_dtype() == "bf16" and self.G8_CHAIN:
+                from .autograd_conv import DecoderChainG8Function
+                if DecoderChainG8Function.usable(x, specs, params):
+                    return DecoderChainG8Function.apply(x.contiguous(), self._packed, tuple(specs), *params)
             return DecoderChainFunction.apply(x.contiguous(), self._packed, tuple(specs), *params)
         up = False
         if precision.get_compute_dtype() in ("bf16", "bf16x3"):

@@ -308,6 +308,93 @@ def conv3x3_dgrad_g8(dy: torch.Tensor, w_packed_t: torch.Tensor, cin: int, dx_g8
     return dx
 
 
+def conv3x3_dgrad_g8_chain(dy: torch.Tensor, w_packed_t: torch.Tensor, cin: int, upsample2x: bool,
+                           dx_gate: Optional[torch.Tensor], want_f32: bool, want_g8: bool, want_g16: bool,
+                           want_bias: bool):
+    """Data gradient of a replicate-padded bf16-mode layer inside the decoder's G8 chain
+    (st_conv3x3_dgrad_bf16_g8_chain): ``dy`` fp32 NCHW or G8 (already gated); ``dx_gate`` = the layer's input
+    activation (fp32 NCHW or G8) or None.  Returns (dx_f32, dx_g8, dx_g16, bias_slabs), None where not requested."""
+    lib = _lib.load()
+    dy_g8 = is_g8(dy)
+    if dy_g8:
+        n, cout, h, w = int(dy.shape[0]), int(dy.shape[1]) * 8, int(dy.shape[2]), int(dy.shape[3])
+    else:
+        n, cout, h, w = (int(v) for v in dy.shape)
+    assert conv_family(w_packed_t, cin, cout) == "bf16"
+    s = 2 if upsample2x else 1
+    hs, ws = h // s, w // s
+    dev = dy.device
+    wsb = lib.st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, PAD_REPLICATE)
+    work = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    dx = torch.empty((n, cin, hs, ws), dtype=torch.float32, device=dev) if want_f32 else None
+    g8 = torch.empty((n, cin // 8, hs, ws, 8), dtype=torch.bfloat16, device=dev) if want_g8 else None
+    g16 = torch.empty((n, cin, hs, ws), dtype=torch.bfloat16, device=dev) if want_g16 else None
+    bias = None
+    if want_bias:
+        slabs = lib.st_conv3x3_dgrad_fold8_bias_slabs(h, w, int(upsample2x))
+        assert slabs > 0
+        bias = torch.empty((n * slabs, cin), dtype=torch.float32, device=dev)
+    gate_g8 = dx_gate is not None and is_g8(dx_gate)
+    if dx_gate is not None:
+        assert tuple(dx_gate.shape) == ((n, cin // 8, hs, ws, 8) if gate_g8 else (n, cin, hs, ws)), "dx_gate shape"
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cin, "bf16") + " dgrad", 2.0 * n * h * w * cin * cout * 9,
+                                 float(dy.numel() * dy.element_size() + 4.0 * n * cin * hs * ws))
+    ptr = lambda t, dt=torch.float32: _lib.dev_ptr(t, "tensor", dt) if t is not None else None      # noqa: E731
+    _lib.check(lib.st_conv3x3_dgrad_bf16_g8_chain(
+        _lib.dev_ptr(dy, "dy", dy.dtype), int(dy_g8), _lib.dev_ptr(w_packed_t, "w_packed_t", w_packed_t.dtype),
+        _lib.dev_ptr(work, "workspace"), ptr(dx_gate, dx_gate.dtype if dx_gate is not None else None), int(gate_g8),
+        ptr(dx), ptr(g8, torch.bfloat16), ptr(g16, torch.bfloat16), ptr(bias), n, cout, h, w, cin, int(upsample2x),
+        _lib.stream_ptr()), "st_conv3x3_dgrad_bf16_g8_chain")
+    if ev is not None:
+        ev.record()
+    return dx, g8, g16, bias
+
+
+def conv3x3_wgrad_pre(x: torch.Tensor, g16: torch.Tensor, bias_slabs: Optional[torch.Tensor], upsample2x: bool,
+                      pad_mode="replicate", dw_out: Optional[torch.Tensor] = None,
+                      db_out: Optional[torch.Tensor] = None):
+    """(dW, dbias) of a bf16-mode layer from the READY operand ``g16`` (bf16 [n, cout, H, W], gated) and the bias
+    partial sums ``bias_slabs`` [slabs, cout] (st_conv3x3_wgrad_bf16_pre); ``x`` fp32 NCHW or G8."""
+    lib = _lib.load()
+    x_g8 = is_g8(x)
+    if x_g8:
+        n, cin, h, w = int(x.shape[0]), int(x.shape[1]) * 8, int(x.shape[2]), int(x.shape[3])
+    else:
+        n, cin, h, w = (int(v) for v in x.shape)
+    cout = int(g16.shape[1])
+    s = 2 if upsample2x else 1
+    assert tuple(g16.shape) == (n, cout, h * s, w * s) and g16.dtype == torch.bfloat16
+    dw = dw_out if dw_out is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    assert tuple(dw.shape) == (cout, cin, 3, 3)
+    db = None
+    if bias_slabs is not None:
+        db = db_out if db_out is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
+        assert tuple(db.shape) == (cout,) and bias_slabs.shape[1] == cout
+    nbytes = lib.st_conv3x3_wgrad_bf16_pre_workspace_bytes(n, cout, cin, h * s, w * s)
+    assert nbytes > 0, "conv3x3_wgrad_pre: shape outside the staged weight-gradient form"
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record("conv3x3_wgrad_bf16_kernel", 2.0 * n * h * s * w * s * cin * cout * 9,
+                                 2.0 * g16.numel() + x.numel() * x.element_size())
+    _lib.check(lib.st_conv3x3_wgrad_bf16_pre(
+        _lib.dev_ptr(x, "x", x.dtype), int(x_g8), _lib.dev_ptr(g16, "g16", torch.bfloat16),
+        _lib.dev_ptr(bias_slabs, "bias_slabs") if bias_slabs is not None else None,
+        int(bias_slabs.shape[0]) if bias_slabs is not None else 0, _lib.dev_ptr(dw, "dw"),
+        _lib.dev_ptr(db, "db") if db is not None else None, _lib.dev_ptr(ws, "workspace"), n, cin, h, w, cout,
+        int(upsample2x), _pad_code(pad_mode), _lib.stream_ptr()), "st_conv3x3_wgrad_bf16_pre")
+    if ev is not None:
+        ev.record()
+    return dw, db
+
+
+def wgrad_pre_ok(n: int, cout: int, cin: int, h: int, w: int) -> bool:
+    """Is [n, cout, h, w] (conv-input dims after the upsample) a shape of the staged weight-gradient form?"""
+    return _lib.load().st_conv3x3_wgrad_bf16_pre_workspace_bytes(n, cout, cin, h, w) > 0
+
+
 def grad_join_g8(shape, chain: Optional[torch.Tensor] = None, chain_pooled: Optional[torch.Tensor] = None,
                  x_gate: Optional[torch.Tensor] = None, add_post: Optional[torch.Tensor] = None,
                  add_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
