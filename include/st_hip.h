@@ -81,6 +81,17 @@ int st_conv3x3_pool_fwd(const float* x, const float* w_packed, const float* bias
                         int n, int cin, int hin, int win, int cout, int pad_mode, int relu,
                         st_stream_t stream);
 
+/* Sub-pixel form of the forward pass of a layer that reads its input through the nearest x2 upsample
+ * (generator.py:92,105,112 -> :93,106,113; replicate padding): output pixel (2i+a, 2j+b) only sees 2 x 2 source
+ * pixels, with the filter rows / columns that land on the same source pixel summed when the weights are packed --
+ * four 2 x 2 convolutions over the LOW-resolution input, 16 instead of 36 multiply-adds per source pixel and channel
+ * pair.  Same result as st_conv3x3_fwd(upsample2x = 1, ST_PAD_REPLICATE) up to fp32 summation order (the summed
+ * weights).  x [n][cin][hin][win] -> y [n][cout][2 hin][2 win].  Packed buffer: st_conv3x3_up2_packed_elems() floats. */
+size_t st_conv3x3_up2_packed_elems(int cout, int cin);
+int st_conv3x3_pack_weights_up2(const float* w_oihw, float* w_packed, int cout, int cin, st_stream_t stream);
+int st_conv3x3_up2_fwd(const float* x, const float* w_packed_up2, const float* bias, float* y, int n, int cin,
+                       int hin, int win, int cout, int relu, st_stream_t stream);
+
 /* Data gradient of the layer above (decoder backward, trainer.py:472; loss-VGG backward).
  *   dy:      [n][cout][h][w]   gradient w.r.t. the layer output (h, w = OUTPUT dims)
  *   y_gate:  nullable; the layer's post-ReLU output: dy is taken as 0 where y_gate <= 0

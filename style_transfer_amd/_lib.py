@@ -22,6 +22,10 @@ SIGNATURES = {
     "st_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_up2_packed_elems": (c_size_t, [c_int, c_int]),
+    "st_conv3x3_pack_weights_up2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "st_conv3x3_up2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p]),
     "st_conv3x3_pool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_void_p]),
     "st_conv3x3_pool_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -20,7 +20,8 @@ def conv3x3_apply(x, weight, bias, cache, key, upsample2x: bool, pad_mode: int, 
     """Fused [nearest x2 upsample] -> pad 1 -> Conv2d(3x3) -> [ReLU]."""
     cout = int(weight.shape[0])
     if not _needs_grad(x, weight, bias):
-        wp = cache.get(key, weight, False, forward_only=True)
+        wp = cache.get(key, weight, False, forward_only=True,
+                       upsample2x=upsample2x and ops._pad_code(pad_mode) == ops.PAD_REPLICATE)
         return ops.conv3x3(x, wp, bias.detach() if bias is not None else None, cout, upsample2x, pad_mode, relu)
     from .autograd_conv import Conv3x3Function
     return Conv3x3Function.apply(x, weight, bias, cache, key, upsample2x, pad_mode, relu)

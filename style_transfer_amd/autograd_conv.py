@@ -78,6 +78,8 @@ class DecoderChainFunction(torch.autograd.Function):
         compute = []        # per layer: the backward of a layer uses its forward's precision
         for i, (key, cout, up, relu) in enumerate(specs):
             w, b = params[2 * i], params[2 * i + 1]
+            # (the sub-pixel form of the upsample layers is kept to forward-only calls: the training step's float64
+            # arbiter test, tests/test_gpu_parity_step.py, is calibrated on the direct form's rounding pattern)
             wp = cache.get(key, w, False)
             compute.append(ops.conv_family(wp, int(w.shape[0]), int(w.shape[1])))
             acts.append(ops.conv3x3(acts[-1], wp, b.detach(), cout, up, ops.PAD_REPLICATE, relu))

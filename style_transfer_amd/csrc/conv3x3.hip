@@ -18,6 +18,7 @@
 //   * The next chunk's global loads are issued before the MFMA phase and written to LDS
 //     after it (register prefetch), several blocks per CU overlap staging with MFMA.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -49,13 +50,20 @@ struct ConvParams {
   int tiles_x, tiles_y, ctiles, xcd_swizzle;
 };
 
-template <int MT, int NT, int WM, int WP>
+// SUB = the sub-pixel form of a conv that reads its input through a nearest x2 upsample (generator.py:92,105,112):
+// output pixel (2i + a, 2j + b) only sees the 2 x 2 source pixels (i - 1 + a .. i + a) x (j - 1 + b .. j + b), with
+// the 3 x 3 filter's rows / columns that fall on the same source pixel summed beforehand (st_conv3x3_pack_weights_up2)
+// -- four 2 x 2 convolutions ("classes" (a, b)) over the LOW-resolution input instead of one 3 x 3 convolution over the
+// upsampled one: 16 instead of 36 multiply-adds per source pixel and channel pair.  A block owns BM channels x (TH x 32)
+// SOURCE pixels; its four waves are the four classes (same channels, same source tile, same staged halo).
+template <int MT, int NT, int WM, int WP, bool SUB = false>
 struct Cfg {
-  static constexpr int BM = 32 * MT * WM;
-  static constexpr int TH = NT * WP;
+  static constexpr int BM = SUB ? 32 * MT : 32 * MT * WM;
+  static constexpr int TH = SUB ? NT : NT * WP;
   static constexpr int HR = TH + 2;
   static constexpr int PLANE = HR * HC;
-  static constexpr int W_ELEMS = 9 * KC * BM;
+  static constexpr int NTAP = SUB ? 16 : 9;       // weight rows per input channel: (class, 2 x 2 tap) or 3 x 3 tap
+  static constexpr int W_ELEMS = NTAP * KC * BM;
   static constexpr int X_ELEMS = KC * PLANE;
   static constexpr int NP = (PLANE + NTHREADS - 1) / NTHREADS;
   static constexpr int NW4 = (W_ELEMS / 4 + NTHREADS - 1) / NTHREADS;
@@ -66,10 +74,11 @@ struct Cfg {
 // The block is single-buffered in LDS (MFMA phase, barrier, LDS-store phase, barrier), so it is the OTHER blocks
 // on the CU that keep the matrix pipe busy during a block's staging phase: at 3 blocks per CU (<= 168 registers,
 // 3 x 43 KB of LDS) the large layers run at 135-137 TFLOP/s instead of 121-126 at 2 (220 registers).
-template <int MT, int NT, int WM, int WP, bool GATE, int OCC>
+template <int MT, int NT, int WM, int WP, bool GATE, int OCC, bool SUB = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv3x3_f32_kernel(ConvParams p) {
-  using C = Cfg<MT, NT, WM, WP>;
+  using C = Cfg<MT, NT, WM, WP, SUB>;
   static_assert(WM * WP == 4, "four waves per block");
+  static_assert(!SUB || !GATE, "sub-pixel form: forward only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;
   float* Xs = smem + C::W_ELEMS;
@@ -77,7 +86,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, O
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave / WP, wp = wave % WP;
+  const int wm = SUB ? 0 : wave / WP, wp = SUB ? 0 : wave % WP;
+  const int cls_a = wave >> 1, cls_b = wave & 1;     // SUB: this wave's output parity class (row, column)
 
   // Block -> (pixel tile, channel tile).  Blocks are dealt round-robin over the 8 XCDs (each with
   // its own L2), so ids that differ by 8 share an XCD: the channel tiles of one pixel tile get
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, O
         _Pragma("unroll") for (int i = 0; i < C::NP; ++i) gr[c][i] = gsrc[soff[i]];    \
       }                                                                                \
     }                                                                                  \
-    const float* wsrc = p.wp + size_t(chunk_) * (9 * KC) * p.cout_pad + m0;            \
+    const float* wsrc = p.wp + size_t(chunk_) * (C::NTAP * KC) * p.cout_pad + m0;      \
     _Pragma("unroll") for (int i = 0; i < C::NW4; ++i)                                 \
         wr[i] = *reinterpret_cast<const f32x4*>(wsrc + woff[i]);                      \
   }
@@ -181,8 +191,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, O
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const float* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li;
-  const float* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li;
+  const float* aPtr = Ws + lh * C::BM + wm * (MT * 32) + li + (SUB ? wave * (4 * KC * C::BM) : 0);
+  const float* bPtr = Xs + lh * C::PLANE + (wp * NT) * HC + li + (SUB ? cls_a * HC + cls_b : 0);
 
   ST_LOAD_CHUNK(0);
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -191,8 +201,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, O
     __syncthreads();
     if (chunk + 1 < p.nchunks) ST_LOAD_CHUNK(chunk + 1);  // in flight during the MFMA phase
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
+    for (int tap = 0; tap < (SUB ? 4 : 9); ++tap) {
+      // SUB: 2 x 2 taps of this wave's class; source row y0 + nt - 1 + a + dy is halo row nt + a + dy (a, b in bPtr)
+      const int dy = SUB ? tap / 2 : tap / 3, dx = SUB ? tap % 2 : tap % 3;
 #pragma unroll
       for (int cp = 0; cp < KC / 2; ++cp) {
         float a[MT], bb[NT];
@@ -211,7 +222,32 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC, O
 
   // ---- epilogue: bias + ReLU, NCHW store (register r of a tile = one channel row) -----
   const int xx = x0 + li;
-  if (NT % 2 == 0 && p.pool) {     // (the 2-row-tile instantiation, NT = 1, is never launched with pool)
+  if constexpr (SUB) {
+    // source pixel (yy, xx) of class (a, b) is output pixel (2 yy + a, 2 xx + b): dword stores at stride 2 whose
+    // other halves come from the partner wave (b ^ 1) of this block -- the lines are completed in the same L2
+    if (xx < p.W) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < p.cout) {
+            const float bv = p.bias ? p.bias[co] : 0.f;
+            float* yrow = p.y + (size_t(b) * p.cout + co) * p.Ho * p.ldo + 2 * xx + cls_b;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int yy = y0 + nt;
+              if (yy < p.H) {
+                float v = acc[mt][nt][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                yrow[size_t(2 * yy + cls_a) * p.ldo] = v;
+              }
+            }
+          }
+        }
+      }
+    }
+  } else if (NT % 2 == 0 && p.pool) {     // (the 2-row-tile instantiation, NT = 1, is never launched with pool)
     // fused MaxPool2d((2,2),(2,2),ceil_mode=True) (generator.py:53,60,73): rows 2k, 2k+1 are two
     // accumulator tiles of this wave, columns 2k, 2k+1 are neighbouring lanes; bias and ReLU commute
     // with the max.  Even lanes write the pooled row (the full-resolution tensor never exists).
@@ -361,6 +397,45 @@ __global__ __launch_bounds__(256) void dgrad_fold4_kernel(const float* __restric
   }
 }
 
+// OIHW -> the sub-pixel layout [cin_pad / KC][(class a, b)(tap dy', dx')][KC][cout_pad]: filter rows / columns that
+// read the same source pixel under the x2 nearest upsample are summed (a = 0: {0}, {1, 2}; a = 1: {0, 1}, {2}).
+__global__ void pack_weights_up2_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin,
+                                        int cout_pad, long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int o = int(e % cout_pad);
+    long long k = e / cout_pad;
+    const int c = int(k % KC);
+    k /= KC;
+    const int t = int(k % 16);
+    const int cg = int(k / 16) * KC + c;
+    const int a = t >> 3, bq = (t >> 2) & 1, dy = (t >> 1) & 1, dx = t & 1;
+    float v = 0.f;
+    if (o < cout && cg < cin) {
+      const int r0 = a == 0 ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), r1 = a == 0 ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+      const int c0 = bq == 0 ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), c1 = bq == 0 ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+      const float* wk = w + (size_t(o) * cin + cg) * 9;
+      for (int r = r0; r <= r1; ++r)
+        for (int q = c0; q <= c1; ++q) v += wk[r * 3 + q];
+    }
+    wp[e] = v;
+  }
+}
+
+template <int MT, int NT, int OCC>
+int launch_conv_sub(ConvParams& p, hipStream_t stream) {
+  using C = Cfg<MT, NT, 2, 2, true>;
+  p.tiles_x = st::cdiv(p.W, TW);
+  p.tiles_y = st::cdiv(p.H, C::TH);
+  const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
+  p.ctiles = st::cdiv(p.cout, C::BM);
+  ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3_up2_fwd: too many tiles (%lld)", ptiles * p.ctiles);
+  p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
+  dim3 grid((unsigned)(ptiles * p.ctiles));
+  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, 2, 2, false, OCC, true>), grid, dim3(NTHREADS), C::LDS_BYTES, stream, p);
+  return st::check_launch("st_conv3x3_up2_fwd");
+}
+
 template <int MT, int NT, int WM, int WP, bool GATE>
 int launch_conv(ConvParams& p, hipStream_t stream) {
   using C = Cfg<MT, NT, WM, WP>;
@@ -490,6 +565,45 @@ extern "C" int st_conv3x3_fwd(const float* x, const float* w_packed, const float
                               int n, int cin, int hin, int win, int cout, int upsample2x,
                               int pad_mode, int relu, st_stream_t stream) {
   return conv3x3_fwd_impl(x, w_packed, bias, y, n, cin, hin, win, cout, upsample2x, pad_mode, relu, 0, stream);
+}
+
+extern "C" size_t st_conv3x3_up2_packed_elems(int cout, int cin) {
+  if (cout <= 0 || cin <= 0) return 0;
+  const size_t cin_pad = size_t(st::cdiv(cin, KC)) * KC;
+  const size_t cout_pad = size_t(st::cdiv(cout, CPAD)) * CPAD;
+  return cin_pad * 16 * cout_pad;
+}
+
+extern "C" int st_conv3x3_pack_weights_up2(const float* w_oihw, float* w_packed, int cout, int cin,
+                                           st_stream_t stream) {
+  ST_REQUIRE(w_oihw && w_packed, "st_conv3x3_pack_weights_up2: null pointer");
+  ST_REQUIRE(cout > 0 && cin > 0, "st_conv3x3_pack_weights_up2: bad dims cout=%d cin=%d", cout, cin);
+  const int cout_pad = st::cdiv(cout, CPAD) * CPAD;
+  const long long total = (long long)st_conv3x3_up2_packed_elems(cout, cin);
+  const int blocks = (int)std::min<long long>(st::cdivll(total, 256), 4096);
+  hipLaunchKernelGGL(pack_weights_up2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, w_packed,
+                     cout, cin, cout_pad, total);
+  return st::check_launch("st_conv3x3_pack_weights_up2");
+}
+
+extern "C" int st_conv3x3_up2_fwd(const float* x, const float* w_packed_up2, const float* bias, float* y, int n,
+                                  int cin, int hin, int win, int cout, int relu, st_stream_t stream) {
+  ST_REQUIRE(x && w_packed_up2 && y, "st_conv3x3_up2_fwd: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
+             "st_conv3x3_up2_fwd: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
+  ST_REQUIRE((long long)hin * win * 4 < (1LL << 31), "st_conv3x3_up2_fwd: plane too large");
+  ConvParams p;
+  p.x = x; p.gate = nullptr; p.wp = w_packed_up2; p.bias = bias; p.y = y;
+  p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
+  p.up = 0; p.H = hin; p.W = win;                      // the staged halo is the SOURCE tile
+  p.Ho = 2 * hin; p.Wo = 2 * win; p.ldo = 2 * win; p.shift = 0; p.pool = 0;
+  p.cout_pad = st::cdiv(cout, CPAD) * CPAD;
+  p.nchunks = st::cdiv(cin, KC);
+  p.pad_zero = 0; p.relu = relu ? 1 : 0;
+  const char* ve = getenv("ST_UP2_VARIANT");        // A/B switch: 1 = the 4-row source tile at two blocks per CU
+  const int variant = ve ? atoi(ve) : 0;
+  if (variant == 1) return launch_conv_sub<2, 4, 2>(p, (hipStream_t)stream);   // 64 ch x (4 x 32) source pixels
+  return launch_conv_sub<2, 2, 3>(p, (hipStream_t)stream);                     // 64 ch x (2 x 32) source pixels
 }
 
 extern "C" int st_conv3x3_pool_fwd(const float* x, const float* w_packed, const float* bias, float* ypool,

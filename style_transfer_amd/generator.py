@@ -52,9 +52,18 @@ class _PackedWeightCache:
         self._c: Dict[Tuple[int, bool], Tuple[int, int, torch.Tensor]] = {}
         self.direct_grads = False     # set by the trainer: weight gradients go straight into its flat bucket
 
+    #: fp32 mode: a layer that reads its input through the x2 upsample runs its FORWARD in the sub-pixel form (four
+    #: 2 x 2 convolutions over the low-resolution input, st_conv3x3_up2_fwd: 16 / 36 of the multiply-adds);
+    #: ST_NO_UP2=1: the direct 3 x 3 form on the upsampled input
+    UP2 = os.environ.get("ST_NO_UP2") is None
+
     def get(self, key, w: torch.Tensor, transpose_flip: bool = False, compute: Optional[str] = None,
-            forward_only: bool = False) -> torch.Tensor:
+            forward_only: bool = False, upsample2x: bool = False) -> torch.Tensor:
+        """``upsample2x``: the forward weights of a replicate-padded layer behind the x2 upsample (fp32 mode: the
+        sub-pixel packing, see UP2)."""
         compute = compute or precision.get_compute_dtype()
+        if upsample2x and compute == "f32" and not transpose_flip and self.UP2:
+            compute = "f32up2"
         if compute == "bf16x3" and forward_only and 3 in (int(w.shape[0]), int(w.shape[1])):
             # the 3-channel layers are HBM-bound: the exact-fp32 vector-ALU kernels (csrc/conv3x3_small.hip)
             # are as fast as any matrix-pipe form, so the fp32-grade mode keeps them exact (forward-only callers:

@@ -57,6 +57,8 @@ def conv_family(w_packed: torch.Tensor, cout: int, cin: int) -> str:
     lib = _lib.load()
     if w_packed.dtype == torch.float32:
         fam, need = "f32", lib.st_conv3x3_packed_elems(cout, cin)
+        if w_packed.numel() == lib.st_conv3x3_up2_packed_elems(cout, cin):
+            fam, need = "f32up2", w_packed.numel()       # sub-pixel packing of an upsample layer (forward only)
     else:
         assert w_packed.dtype == torch.bfloat16, f"packed weights must be fp32 or bf16, got {w_packed.dtype}"
         need = lib.st_conv3x3_packed_elems_bf16(cout, cin)
@@ -67,7 +69,7 @@ def conv_family(w_packed: torch.Tensor, cout: int, cin: int) -> str:
     return fam
 
 
-_SUFFIX = {"f32": "", "bf16": "_bf16", "bf16x3": "_bf16x3"}
+_SUFFIX = {"f32": "", "f32up2": "", "bf16": "_bf16", "bf16x3": "_bf16x3"}
 
 
 def conv_kernel_name(cout: int, bf16=False) -> str:
@@ -75,6 +77,8 @@ def conv_kernel_name(cout: int, bf16=False) -> str:
     ``bf16``: bool or a family name."""
     if bf16 == "bf16x3":
         return "conv3x3_bf16x3_kernel<1,4,2,4>"
+    if bf16 == "f32up2":
+        return "conv3x3_f32_kernel<2,2,sub-pixel>"
     if bf16 == "f32":
         bf16 = False
     if bf16:
@@ -103,6 +107,12 @@ def pack_conv3x3_weights(w: torch.Tensor, transpose_flip: bool = False, compute:
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = w.detach()
     pc_out, pc_in = (cin, cout) if transpose_flip else (cout, cin)
+    if compute == "f32up2":
+        assert not transpose_flip, "the sub-pixel packing is a forward-only form"
+        packed = torch.empty(lib.st_conv3x3_up2_packed_elems(cout, cin), dtype=torch.float32, device=w.device)
+        _lib.check(lib.st_conv3x3_pack_weights_up2(_lib.dev_ptr(w, "w"), _lib.dev_ptr(packed, "packed"), cout, cin,
+                                                   _lib.stream_ptr()), "st_conv3x3_pack_weights_up2")
+        return packed
     if compute in ("bf16", "bf16x3"):
         elems = getattr(lib, "st_conv3x3_packed_elems" + _SUFFIX[compute])
         pack = getattr(lib, "st_conv3x3_pack_weights" + _SUFFIX[compute])
@@ -129,6 +139,18 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     s = 2 if upsample2x else 1
     y = torch.empty((n, cout, h * s, w * s), dtype=torch.float32, device=x.device)
     ev = None
+    if bf16 == "f32up2":
+        assert upsample2x and _pad_code(pad_mode) == PAD_REPLICATE, "sub-pixel weights: an upsample layer, replicate pad"
+        if KERNEL_TIMER.enabled:       # EXECUTED work: 4 classes x 4 taps per source pixel (36 in the direct form)
+            ev = KERNEL_TIMER.record(conv_kernel_name(cout, bf16), 2.0 * n * h * w * cin * cout * 16,
+                                     4.0 * (x.numel() + y.numel()))
+        _lib.check(lib.st_conv3x3_up2_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(w_packed, "w_packed"),
+                                          _lib.dev_ptr(bias, "bias") if bias is not None else None,
+                                          _lib.dev_ptr(y, "y"), n, cin, h, w, cout, int(relu), _lib.stream_ptr()),
+                   "st_conv3x3_up2_fwd")
+        if ev is not None:
+            ev.record()
+        return y
     if KERNEL_TIMER.enabled:
         ev = KERNEL_TIMER.record(conv_kernel_name(cout, bf16), 2.0 * n * h * s * w * s * cin * cout * 9,
                                  4.0 * (x.numel() + y.numel()))
