@@ -48,7 +48,8 @@ def capture_sets(layout, sets: Sequence[Sequence[int]]):
 
 
 class VGGChainFunction(torch.autograd.Function):
-    """forward(x, net, last_all, P, Q) -> one fp32 tensor per key of ``chain_keys(...)``, in that order."""
+    """forward(x, net, last_all, P, Q) -> one fp32 tensor per key of ``keys(layout, last_all, P, Q)``, in that order
+    ((P, Q) = capture_sets(layout, sets)); backward: see the module docstring."""
 
     @staticmethod
     def keys(layout, last_all, pre, post) -> List[Tuple[str, int]]:

@@ -8,6 +8,6 @@ char* error_buffer() {
 }
 }  // namespace st
 
-extern "C" int st_version(void) { return 100; }  // 0.1.0
+extern "C" int st_version(void) { return 120; }  // 0.1.20: + G8 training chains, sub-pixel upsample forward
 
 extern "C" const char* st_last_error(void) { return st::error_buffer(); }

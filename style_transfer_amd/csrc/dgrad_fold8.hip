@@ -59,26 +59,35 @@ __global__ __launch_bounds__(256) void dgrad_fold8_kernel(Fold8Params p) {
     const bool left = j0 == 0, right = j0 + 4 == p.ws;
     float s[8][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float* src = src0 + j * plane_p;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      for (int u = u0; u <= u1; ++u) {
-        const float* r = src + size_t(u + 1) * Wp + (UP ? 2 * j0 : j0);
-        const f4 a = *reinterpret_cast<const f4*>(r);
+    for (int j = 0; j < 8; ++j) s[j][0] = s[j][1] = s[j][2] = s[j][3] = 0.f;
+    // rows outermost: the loads of all eight channels of a padded row are independent and issue back to back (with the
+    // channel loop outside, each channel's loads waited behind the row loop's dynamic trip count: 8 serial latencies)
+    for (int u = u0; u <= u1; ++u) {
+      const float* r0 = src0 + size_t(u + 1) * Wp + (UP ? 2 * j0 : j0);
+      f4 a[8], bb[8];
+      float e0[8], e1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* r = r0 + j * plane_p;
+        a[j] = *reinterpret_cast<const f4*>(r);
+        if (UP) bb[j] = *reinterpret_cast<const f4*>(r + 4);
+        e0[j] = r[UP ? 8 : 4];
+        e1[j] = right ? r[UP ? 9 : 5] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
         if (UP) {
-          const f4 bb = *reinterpret_cast<const f4*>(r + 4);
-          s0 += a[1] + a[2] + (left ? a[0] : 0.f);
-          s1 += a[3] + bb[0];
-          s2 += bb[1] + bb[2];
-          s3 += bb[3] + r[8] + (right ? r[9] : 0.f);
+          s[j][0] += a[j][1] + a[j][2] + (left ? a[j][0] : 0.f);
+          s[j][1] += a[j][3] + bb[j][0];
+          s[j][2] += bb[j][1] + bb[j][2];
+          s[j][3] += bb[j][3] + e0[j] + e1[j];
         } else {
-          s0 += a[1] + (left ? a[0] : 0.f);
-          s1 += a[2];
-          s2 += a[3];
-          s3 += r[4] + (right ? r[5] : 0.f);
+          s[j][0] += a[j][1] + (left ? a[j][0] : 0.f);
+          s[j][1] += a[j][2];
+          s[j][2] += a[j][3];
+          s[j][3] += e0[j] + e1[j];
         }
       }
-      s[j][0] = s0; s[j][1] = s1; s[j][2] = s2; s[j][3] = s3;
     }
     const size_t pix = size_t(i) * p.ws + j0;                       // first of the 4 pixels inside a source plane
     if (p.gate_g8) {
