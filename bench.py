@@ -508,6 +508,62 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
     }
 
 
+def run_hires(ctx: Ctx, steps: int = 3, warmup: int = 1, side: int = 2048):
+    """BASELINE configs[4]: one 2048x2048 pair per GPU, alpha in {0.5, 1, 1.5} (three stylisations per step), fp32.
+    256 KB feature planes: the AdaIN launches are adain_big_kernel (one plane per block held in registers)."""
+    from oracle import ref_ops as R     # seeded synthetic weights only
+    from style_transfer_amd import ops
+    from style_transfer_amd.generator import Decoder, Encoder
+    from style_transfer_amd.pipeline import stylize
+    from style_transfer_amd.transformer import AdaIN
+
+    dev = ctx.dev
+    enc = Encoder(weights=R.make_encoder_state(0)).to(dev).eval()
+    dec = Decoder().to(dev).eval()
+    dec.load_state_dict(R.make_decoder_state(1))
+    ada = AdaIN().to(dev)
+    g = torch.Generator().manual_seed(4321 + ctx.rank)
+    content = torch.rand(1, 3, side, side, generator=g).to(dev)
+    style = torch.rand(1, 3, side, side, generator=g).to(dev)
+    alphas = (0.5, 1.0, 1.5)
+
+    def step():
+        out = None
+        for a in alphas:
+            out = stylize(enc, dec, ada, content, style, alpha=a)
+        return out
+    for _ in range(warmup):
+        step()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    ctx.barrier()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(out).all()
+    ops.KERNEL_TIMER.start()
+    step()
+    recs = [r for r in ops.KERNEL_TIMER.stop() if r["kernel"] == "adain_fwd"]
+    n_img = ctx.world * len(alphas) * steps
+    e_f, d_f = encoder_decoder_flops(side)
+    per_img = 2 * e_f + d_f
+    ad_us = sum(r["ms"] for r in recs) / max(1, len(recs)) * 1e3
+    ad_bytes = recs[0]["bytes"] if recs else 0.0
+    return {"metric": "stylized 2048x2048 img/s (inference)", "value": round(n_img / elapsed, 3), "unit": "img/s",
+            "n_gpus": ctx.world, "steps": steps, "warmup": warmup, "ms_per_image": round(elapsed / (len(alphas) * steps) * 1e3, 2),
+            "dtype": "f32", "scaling": "weak",
+            "config": {"workload": f"BASELINE configs[4]: one {side}x{side} content/style pair per GPU, alpha sweep "
+                                   "0.5 / 1 / 1.5 (three stylisations per step), fp32, images sharded with no collective",
+                       "batch_per_gpu": 1, "side": side, "gflop_per_image": round(per_img / 1e9, 1)},
+            "model_tflops": round(n_img / elapsed * per_img / 1e12, 2),
+            "roofline_adain": {"bound": "hbm", "kernel": "adain_big_kernel (256 KB planes)",
+                               "achieved": round(ad_bytes / max(1e-9, ad_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ad_bytes / max(1e-9, ad_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                               "avg_launch_us": round(ad_us, 2), "avg_launch_mbytes": round(ad_bytes / 1e6, 2),
+                               "method": "HIP event pair around each of the step's three launches (an event pair costs "
+                                         "about 8 us on a launch this short)"}}
+
+
 def run_train(ctx: Ctx, args, use_vincent: bool, compute: str = "f32", batch: int = None, side: int = None,
               hip_graph: bool = False):
     from oracle import ref_ops as R     # seeded synthetic weights only
@@ -615,6 +671,7 @@ def main():
     ap.add_argument("--no-hip-graph", action="store_true", help="skip the HIP-graph-replay variants of the train legs")
     ap.add_argument("--compute", choices=["f32", "bf16", "bf16x3"], default="f32",
                     help="conv compute precision of the main legs (profiling aid; the headline legs are f32)")
+    ap.add_argument("--no-hires", action="store_true", help="skip the 2048x2048 alpha-sweep leg (BASELINE configs[4])")
     ap.add_argument("--no-bf16", action="store_true",
                     help="skip the bf16 (BASELINE configs[3] shape) and bf16x3 compute-mode legs")
     args = ap.parse_args()
@@ -682,6 +739,8 @@ def main():
             tgt["hip_graph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "launch")}
         except Exception as e:      # noqa: BLE001
             tgt["hip_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if args.mode in ("both", "infer") and not args.no_hires and line:
+        line["hires"] = extra(run_hires, ctx)
     if ctx.world == 1 and args.mode == "both" and not args.no_aux:
         line.update(roofline_aux(ctx))
     if ctx.rank == 0:
