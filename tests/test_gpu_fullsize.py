@@ -125,3 +125,51 @@ def test_stylize_configs1_batch_matches_oracle_on_decoder_side_crops(models):
         br = R.decoder_forward(t[n:n + 1, :, -24:, -24:].cpu(), dec_sd)
         assert rel_err(out[n:n + 1, :, :128, :128], tl[:, :, :128, :128]) < 1e-3
         assert rel_err(out[n:n + 1, :, -128:, -128:], br[:, :, -128:, -128:]) < 1e-3
+
+
+def test_bf16_g8_training_chains_at_the_configs3_size():
+    """BASELINE configs[3] per-GPU shape (B=8, 512x512, bf16): decoder + loss VGG on the decoded image through the G8
+    chains (autograd_conv.DecoderChainG8Function, autograd_vgg.VGGChainFunction) against the per-layer /
+    fp32-activation forms -- bit-identical taps, input gradient and weight gradients at the size where the persistent
+    kernels walk thousands of tiles and offsets pass 2^31 bytes."""
+    import warnings
+    from style_transfer_amd import precision
+    from style_transfer_amd.generator import Decoder
+    from style_transfer_amd.loss_network import VGG19FeatureExtractor
+    sets = [[21], [2, 7, 14, 19, 25]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vgg = VGG19FeatureExtractor([2, 7, 14, 19, 21, 25], weights=R.make_loss_vgg_state(2, upto=25)).cuda()
+    dec = Decoder().cuda()
+    dec.load_state_dict(R.make_decoder_state(1))
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.relu(torch.randn(8, 512, 64, 64, generator=g)).cuda()
+    wts = [0.7, -0.3, 0.5, 1.1, -0.9, 0.4]
+
+    def run(chains):
+        dec.G8_CHAIN = vgg.GRAD_CHAIN = chains
+        for p in dec.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        with precision.compute_dtype("bf16"):
+            img = dec(x)
+            taps = [t for s in vgg.forward_multi(img, sets) for t in s]
+            loss = sum(w * (t * t).mean() for w, t in zip(wts, taps))
+            loss.backward()
+        out = ([t.detach().clone() for t in taps[-2:]], x.grad.clone(), [p.grad.clone() for p in dec.parameters()])
+        del taps, img, loss
+        return out
+    try:
+        ref = run(False)
+        torch.cuda.empty_cache()
+        got = run(True)
+    finally:
+        dec.G8_CHAIN = vgg.GRAD_CHAIN = True
+    for a, b in zip(got[0], ref[0]):
+        assert torch.equal(a, b)
+    assert float(ref[1].abs().max()) > 0 and torch.equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        if a.dim() == 4:
+            assert torch.equal(a, b)
+        else:
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))
