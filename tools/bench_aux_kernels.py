@@ -115,6 +115,46 @@ def main():
         line(f"mean/std style loss fwd+bwd  [{b},{c},{hw},{hw}]  (graph replay)", timeit(graphed(sb)),
              nbytes=4.0 * 4 * f.numel())
 
+    # ---- the G8 glue kernels of the bf16 training chains (configs[3] per-GPU shapes: B=8, 512x512 image) ------------
+    # algorithmic bytes: every source element read once (fp32 = 4 B), every result written once (G8 / bf16 = 2 B)
+    for c, hw in ((64, 512), (128, 256), (256, 128)):
+        b = 8
+        x = torch.relu(torch.randn(b, c, hw, hw, device=dev, generator=g))
+        post = torch.randn(b, c, hw, hw, device=dev, generator=g)
+        pooled = torch.randn(b, c, hw // 2, hw // 2, device=dev, generator=g)
+        n = x.numel()
+        with torch.no_grad():
+            line(f"maxpool2x2 -> G8  [{b},{c},{hw},{hw}]", timeit(lambda: ops.maxpool2x2_g8(x)), nbytes=4.0 * n + 0.5 * n)
+            line(f"grad join through the pool (x, tap grad, pooled grad -> G8)  [{b},{c},{hw},{hw}]",
+                 timeit(lambda: ops.grad_join_g8(x.shape, chain_pooled=pooled, x_gate=x, add_post=post)),
+                 nbytes=4.0 * n * 2 + 1.0 * n + 2.0 * n)
+            line(f"grad join (chain + tap grad, gate -> G8)  [{b},{c},{hw},{hw}]",
+                 timeit(lambda: ops.grad_join_g8(x.shape, chain=post, x_gate=x, add_post=post)),
+                 nbytes=4.0 * n * 3 + 2.0 * n)
+    for cin, hw, up in ((64, 512, False), (64, 512, True), (128, 256, False), (256, 128, True)):
+        b, cout = 8, cin
+        wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        wpt = ops.pack_conv3x3_weights(wt, True, "bf16")
+        dy = ops.to_g8(torch.randn(b, cout, hw, hw, device=dev, generator=g))
+        s_ = 2 if up else 1
+        gate = ops.to_g8(torch.relu(torch.randn(b, cin, hw // s_, hw // s_, device=dev, generator=g)))
+
+        def dg():
+            return ops.conv3x3_dgrad_g8_chain(dy, wpt, cin, up, gate, want_f32=False, want_g8=True, want_g16=True,
+                                              want_bias=True)
+        with torch.no_grad():
+            t_all = timeit(dg)
+        # the fold alone = the call minus its GEMM (the same GEMM writing fp32 through the forward entry point)
+        wp_f = ops.pack_conv3x3_weights(wt, False, "bf16")
+        with torch.no_grad():
+            t_gemm = timeit(lambda: ops.conv3x3_g8(dy, wp_f, None, cin, False, ops.PAD_ZERO, relu=False, y_g8=False))
+        n_pad = b * cin * (hw + 2) * ((hw + 2 + 3) // 4 * 4)
+        n_src = b * cin * (hw // s_) ** 2
+        line(f"dgrad G8 chain call, {cout}->{cin} at {hw}x{hw}{' (x2 upsample below)' if up else ''}: GEMM + fold8",
+             t_all, flops=2.0 * b * hw * hw * cin * cout * 9)
+        line("   of which dgrad_fold8 (padded fp32 + G8 gate -> G8 + bf16 G + bias sums), by difference",
+             max(t_all - t_gemm, 0.1), nbytes=4.0 * n_pad + 2.0 * n_src + 2.0 * n_src * 2)
+
 
 if __name__ == "__main__":
     main()
