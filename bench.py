@@ -102,6 +102,36 @@ def encoder_decoder_flops(side: int):
     return enc, dec
 
 
+def decoder_upsample_layer_flops(side: int) -> float:
+    """Algorithmic FLOPs per image of the three decoder convs that read a nearest x2 upsampled input
+    (generator.py:92-93, 105-106, 112-113).  In forward-only fp32 calls they run in the sub-pixel form
+    (st_conv3x3_up2_fwd): 16 instead of 36 multiply-adds per source pixel and channel pair, same result."""
+    from oracle.ref_ops import DECODER_CONVS, DECODER_UP_AFTER, ENCODER_POOL_AFTER
+    h = side
+    for _ in ENCODER_POOL_AFTER:
+        h = (h + 1) // 2
+    f, after_up = 0.0, False
+    for idx, cin, cout in DECODER_CONVS:
+        if after_up:
+            f += 2.0 * h * h * cin * cout * 9
+        after_up = idx in DECODER_UP_AFTER
+        if after_up:
+            h *= 2
+    return f
+
+
+def executed_flops_per_image(side: int, compute: str = "f32") -> float:
+    """FLOPs the inference kernels actually EXECUTE per stylised image: the algorithmic 2E + D minus the 20/36 of the
+    three upsample layers' multiply-adds that the sub-pixel form does not perform (fp32 forward-only calls, unless
+    ST_NO_UP2 is set; the bf16 modes run the direct form)."""
+    from style_transfer_amd.generator import _PackedWeightCache
+    e_f, d_f = encoder_decoder_flops(side)
+    total = 2 * e_f + d_f
+    if compute == "f32" and _PackedWeightCache.UP2:
+        total -= decoder_upsample_layer_flops(side) * 20.0 / 36.0
+    return total
+
+
 def loss_vgg_flops(side: int, upto: int) -> float:
     from oracle.ref_ops import VGG19_FEATURES
     f, h = 0.0, side
@@ -417,6 +447,7 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
     value = ctx.world * args.batch * args.steps / elapsed
     e_f, d_f = encoder_decoder_flops(args.side)
     per_img = 2 * e_f + d_f
+    per_img_exec = executed_flops_per_image(args.side, compute)
 
     if compute in ("bf16", "bf16x3"):
         x3 = compute == "bf16x3"
@@ -438,6 +469,7 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
                                         "fp32 NCHW at the encoder/AdaIN/decoder boundaries, bf16 channel-group (G8) "
                                         "activations between the convs of each network"), "batch_per_gpu": args.batch, "side": args.side},
                 "model_tflops": round(value * per_img / 1e12, 2),
+                "model_tflops_executed": round(value * per_img_exec / 1e12, 2),
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                              "traffic": round(pmc_traffic("conv3x3_bf16_kernel<2,4,2,4,false,false,false,false,true,true")[0])
@@ -470,6 +502,9 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
                       "launch gaps on some boxes), so all_conv_time_frac_of_step relates two different loops and "
                       "may exceed 1",
             "ms_per_step_instrumented": round(elapsed_ev / args.steps * 1e3, 3)}
+    roof["method"] += ("; FLOPs per launch are the EXECUTED ones: the sub-pixel launches of the three upsample layers "
+                       "(conv3x3_f32_kernel SUB form) count 16 multiply-adds per source pixel and channel pair, not the 36 "
+                       "of the direct form they replace")
     ad = [r for r in records if r["kernel"].startswith("adain")]
     ad_bytes = sum(r["bytes"] for r in ad)
     ad_secs = sum(r["ms"] for r in ad) * 1e-3
@@ -502,8 +537,12 @@ def run_inference(ctx: Ctx, args, compute: str = "f32"):
                                "fp32 per GPU, 2x VGG19-relu4_1 encoder + AdaIN + decoder, alpha=1",
                    "batch_per_gpu": args.batch, "side": args.side,
                    "parallelism": f"images sharded x{ctx.world}, no collective",
-                   "gflop_per_image": round(per_img / 1e9, 2)},
+                   "gflop_per_image": round(per_img / 1e9, 2),
+                   "executed_gflop_per_image": round(per_img_exec / 1e9, 2)},
         "model_tflops": round(value * per_img / 1e12, 2),
+        "model_tflops_executed": round(value * per_img_exec / 1e12, 2),
+        "model_tflops_note": "model_tflops counts the algorithmic 2E + D FLOPs per image (SURVEY 8d); "
+                             "model_tflops_executed counts what the kernels perform (sub-pixel upsample layers: 16/36)",
         "roofline": roof, "roofline_adain": roof_adain,
     }
 
@@ -547,6 +586,7 @@ def run_hires(ctx: Ctx, steps: int = 3, warmup: int = 1, side: int = 2048):
     n_img = ctx.world * len(alphas) * steps
     e_f, d_f = encoder_decoder_flops(side)
     per_img = 2 * e_f + d_f
+    per_img_exec = executed_flops_per_image(side, "f32")
     ad_us = sum(r["ms"] for r in recs) / max(1, len(recs)) * 1e3
     ad_bytes = recs[0]["bytes"] if recs else 0.0
     return {"metric": "stylized 2048x2048 img/s (inference)", "value": round(n_img / elapsed, 3), "unit": "img/s",
@@ -554,8 +594,10 @@ def run_hires(ctx: Ctx, steps: int = 3, warmup: int = 1, side: int = 2048):
             "dtype": "f32", "scaling": "weak",
             "config": {"workload": f"BASELINE configs[4]: one {side}x{side} content/style pair per GPU, alpha sweep "
                                    "0.5 / 1 / 1.5 (three stylisations per step), fp32, images sharded with no collective",
-                       "batch_per_gpu": 1, "side": side, "gflop_per_image": round(per_img / 1e9, 1)},
+                       "batch_per_gpu": 1, "side": side, "gflop_per_image": round(per_img / 1e9, 1),
+                       "executed_gflop_per_image": round(per_img_exec / 1e9, 1)},
             "model_tflops": round(n_img / elapsed * per_img / 1e12, 2),
+            "model_tflops_executed": round(n_img / elapsed * per_img_exec / 1e12, 2),
             "roofline_adain": {"bound": "hbm", "kernel": "adain_big_kernel (256 KB planes)",
                                "achieved": round(ad_bytes / max(1e-9, ad_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ad_bytes / max(1e-9, ad_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

@@ -386,7 +386,7 @@ int st_cov_bwd(const float* x, const float* mean, const float* gcov, const float
  * VincentStyleLoss.l2wass_dist (losses.py:69, 73, 78) for the style layers with <= 128 channels ---------------
  * a: [batch][c][c] symmetric (both triangles are read and averaged); w: [batch][c] eigenvalues in ascending
  * order; v: [batch][c][c] row-major, COLUMN j is the eigenvector of w[j] (a = v diag(w) v^T); sweeps: nullable,
- * [batch] number of Jacobi sweeps used (== max_sweeps means "did not converge", the analogue of LAPACK's info).
+ * [batch] number of Jacobi sweeps used; max_sweeps + 1 means "did not converge" (the analogue of LAPACK's info).
  * One workgroup per matrix, matrix and eigenvectors resident in LDS, parallel-ordered cyclic Jacobi; c even,
  * 2 <= c <= st_syevj_small_max_dim() (128).  Larger matrices stay on rocSOLVER's syevd (style_transfer_amd/eigh.py). */
 int st_syevj_small_max_dim(void);

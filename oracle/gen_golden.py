@@ -83,15 +83,83 @@ def hist_options(L, out_dir):
     print("hist_options.npz", os.path.getsize(os.path.join(out_dir, "hist_options.npz")), "bytes")
 
 
+def custom_transforms(ref_root, out_dir):
+    """The reference's two custom transforms (src/utils/custom_transform.py:9-46) run from its own module.  The module
+    imports ``torchvision.transforms`` (absent from this image) at the top and calls exactly one torchvision function,
+    ``TF.to_tensor`` on the uint8 HWC array it has just built (:26): the stand-in module's ``to_tensor`` RECORDS that
+    array (the last value the reference itself computes) and returns the documented uint8 -> [0, 1] CHW tensor.
+    Stored: inputs, numpy seeds, the recorded uint8 arrays, the pass-through cases, and RGBToGrayscaleStacked outputs
+    (blue weight 0.144 as written at :41).  torchvision's own ops are NOT stood in for: they stay parity-unpinned."""
+    os.chdir(ref_root)
+    sys.path.insert(0, "./")
+    captured = []
+
+    def to_tensor(arr):
+        captured.append(np.array(arr, copy=True))
+        return torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).to(torch.float32).div(255)
+
+    tv = sys.modules.get("torchvision") or types.ModuleType("torchvision")
+    tvt = sys.modules.get("torchvision.transforms") or types.ModuleType("torchvision.transforms")
+    tvtt = types.ModuleType("torchvision.transforms.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvf.to_tensor = to_tensor
+    tv.transforms, tvt.transforms, tvt.functional = tvt, tvtt, tvf
+    for name, mod in (("torchvision", tv), ("torchvision.transforms", tvt), ("torchvision.transforms.transforms", tvtt),
+                      ("torchvision.transforms.functional", tvf)):
+        sys.modules[name] = mod
+    import matplotlib
+    matplotlib.use("Agg")
+    import src.utils.custom_transform as CT
+
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    imgs = {"a": torch.rand(3, 24, 20, generator=g), "b": torch.rand(3, 37, 45, generator=g) * 0.6 + 0.2,
+            "c": torch.rand(1, 3, 16, 16, generator=g)}          # c: the leading 1 the reference squeezes away (:18)
+    for k, v in imgs.items():
+        out[f"img_{k}"] = _np(v)
+    # RGBToGrayscaleStacked(enable) -- :32-46
+    for k in ("a", "b"):
+        out[f"gray_on_{k}"] = _np(CT.RGBToGrayscaleStacked(True)(imgs[k].clone()))
+        out[f"gray_off_{k}"] = _np(CT.RGBToGrayscaleStacked(False)(imgs[k].clone()))
+    # AddGaussianNoise -- :9-29, train.py:131's settings and the class defaults; seeds chosen so that both the noisy
+    # and the pass-through branch occur
+    cases = []
+    for k, kw, seeds in (("a", dict(mean=0.5, sigma_range=(0., 0.08), p=0.5), (0, 1, 2, 3, 4, 5)),
+                         ("b", dict(mean=0.5, sigma_range=(0., 0.08), p=0.9), (10, 11)),
+                         ("c", dict(), (20, 21, 22, 23))):
+        t = CT.AddGaussianNoise(**kw)
+        for seed in seeds:
+            np.random.seed(seed)
+            captured.clear()
+            res = t(imgs[k].clone())
+            tag = f"noise_{k}_{seed}"
+            out[f"{tag}_applied"] = np.bool_(len(captured) == 1)
+            if captured:
+                assert captured[0].dtype == np.uint8
+                out[f"{tag}_u8"] = captured[0]
+            else:
+                assert torch.equal(res, imgs[k])
+            cases.append((k, seed, kw.get("mean", 0.0), *kw.get("sigma_range", (0.0, 0.06)), kw.get("p", 0.5)))
+    out["noise_cases"] = np.array([(ord(k), s, m, lo, hi, p) for k, s, m, lo, hi, p in cases], dtype=np.float64)
+    path = os.path.join(out_dir, "transforms.npz")
+    np.savez_compressed(path, **out)
+    n_app = sum(bool(out[f"noise_{k}_{s}_applied"]) for k, s, *_ in cases)
+    print("transforms.npz", os.path.getsize(path), "bytes;", n_app, "of", len(cases), "noise cases applied")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default=None, choices=[None, "hist_options"],
-                    help="write just this file (added in round 2; the others stay as generated in round 1)")
+    ap.add_argument("--only", default=None, choices=[None, "hist_options", "transforms"],
+                    help="write just this file (hist_options: round 2, transforms: round 3; the others stay as "
+                         "generated in round 1)")
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
+    if args.only == "transforms":
+        custom_transforms(args.ref, out_dir)
+        return
     G, T, L = _import_reference(args.ref)
     torch.set_num_threads(8)
     if args.only == "hist_options":

@@ -65,21 +65,24 @@ __device__ __forceinline__ void cov_tile(const float* __restrict__ xb, const flo
     Mi[tid] = mb[min(i0 + tid, C - 1)];
     Mj[tid] = mb[min(j0 + tid, C - 1)];
   }
-  // Buffer loads: ONE per-lane offset (this wave's first row + the chunk's pixel) and the row in the scalar offset,
-  // so no per-row address registers exist (as hoisted loop invariants they cost 64-128 registers and spilled).
-  // Rows past C and pixels past n are out of the image's range or belong to the next row: never faulting, and
+  // Buffer loads: ONE per-lane offset (the chunk's pixel, clamped to n - 1) and the row (clamped to C - 1, wave-uniform)
+  // in the scalar offset, so no per-row address registers exist (as hoisted loop invariants they cost 64-128
+  // registers and spilled).  The hardware range check covers the per-lane offset only, NOT the scalar offset, so
+  // both clamps are explicit: every address lies inside this image's C x n floats; the clamped duplicates are
   // masked at the LDS store.
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(xb), 0, int(unsigned(size_t(C) * n * sizeof(float))), 0x00020000);
   const unsigned row_bytes = unsigned(n) * 4u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   float vi[R], vj[DIAG ? 1 : R];
   auto load = [&](int ch) {                       // coalesced 256-B row segments
-    const int vo = int(unsigned(wave) * row_bytes + unsigned(ch * KN + lane) * 4u);
+    const int vo = int(unsigned(min(ch * KN + lane, n - 1)) * 4u);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      vi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, int(unsigned(i0 + 4 * r) * row_bytes), 0));
+      const int ri = min(i0 + wave_u + 4 * r, C - 1), rj = min(j0 + wave_u + 4 * r, C - 1);
+      vi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, int(unsigned(ri) * row_bytes), 0));
       if (!DIAG)
-        vj[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, int(unsigned(j0 + 4 * r) * row_bytes), 0));
+        vj[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, int(unsigned(rj) * row_bytes), 0));
     }
   };
   if (c_begin < c_end) load(c_begin);
@@ -284,7 +287,7 @@ extern "C" int st_cov_fwd(const float* x, const float* mean, float* cov, float* 
                           int n, st_stream_t stream) {
   ST_REQUIRE(x && mean && cov && workspace, "st_cov_fwd: null pointer");
   ST_REQUIRE(b > 0 && c > 0 && n > 0, "st_cov_fwd: bad dims b=%d c=%d n=%d", b, c, n);
-  ST_REQUIRE((long long)(c + 128) * n * 4 < (1LL << 31), "st_cov_fwd: one image of %d x %d floats exceeds the 2 GB a buffer offset spans", c, n);
+  ST_REQUIRE((long long)c * n * 4 < (1LL << 31), "st_cov_fwd: one image of %d x %d floats exceeds the 2 GB a buffer offset spans", c, n);
   const Plan p = plan_for(b, c, n);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.tiles * (p.tiles + 1) / 2, p.nsplit, b);

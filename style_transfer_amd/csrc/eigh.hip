@@ -1,4 +1,4 @@
-// Batched symmetric eigendecomposition of SMALL matrices (C <= 128), one workgroup per matrix, everything in LDS:
+// Batched symmetric eigendecomposition of SMALL matrices (even C <= 128), one workgroup per matrix, everything in LDS:
 // the eigh / eigvalsh calls of VincentStyleLoss.l2wass_dist (losses.py:69,73,78) for the 64- and 128-channel style
 // layers (relu1_2, relu2_2).  rocSOLVER's syevd runs those sizes as a chain of hundreds of tiny launches (4.3 ms for
 // [8,64,64], 2.0 ms for [8,128,128]); a 64x64 matrix and its eigenvector matrix are 33 KB -- they fit one CU's LDS.
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(EighCfg<CMAX>::NT) void syevj_small_kernel(const fl
   constexpr int SLOTS = NT / CMAX;
   const int line = tid & (CMAX - 1), slot = tid / CMAX;
   int sweep = 0;
+  bool converged = false;
   for (; sweep < max_sweeps; ++sweep) {
     if (tid == 0) flag[0] = 0.f;
     __syncthreads();
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(EighCfg<CMAX>::NT) void syevj_small_kernel(const fl
       }
       __syncthreads();
     }
-    if (flag[0] == 0.f) { ++sweep; break; }        // uniform: read after the round's barriers
+    if (flag[0] == 0.f) { ++sweep; converged = true; break; }   // uniform: read after the round's barriers
     __syncthreads();
   }
   __syncthreads();
@@ -169,7 +170,9 @@ __global__ __launch_bounds__(EighCfg<CMAX>::NT) void syevj_small_kernel(const fl
     const int i = e / c, j = e - i * c;
     vb[(size_t)i * c + rank[j]] = V[i * LD + j];
   }
-  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = sweep;
+  // sweeps used (the last, rotation-free one included), or max_sweeps + 1 if the loop ran out without one: a
+  // decomposition that converges in its last permitted sweep reports max_sweeps and is NOT a failure
+  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = converged ? sweep : max_sweeps + 1;
 }
 
 }  // namespace

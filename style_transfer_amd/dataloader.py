@@ -34,21 +34,23 @@ class STDataset(Dataset):
     def __len__(self) -> int:
         return min(len(self.content_urls), len(self.style_urls))
 
-    def __getitem__(self, idx) -> Dict:
-        content_url, style_url = self.content_urls[idx], self.style_urls[idx]
-        if self.url_only:
-            return {'content_image': content_url, 'style_image': style_url}
+    @staticmethod
+    def _decode(url, transform):
+        """One image file -> RGB PIL image -> ``transform`` (if any).  A file PIL cannot read raises IOError after the
+        reference's warning (src/data/dataloader.py:45-47 warns and then raises)."""
         try:
-            content_image = Image.open(content_url).convert('RGB')
-            style_image = Image.open(style_url).convert('RGB')
+            image = Image.open(url).convert('RGB')
         except IOError:
             warnings.warn("IO Error, watch out !")
             raise
-        if self.transform_content is not None:
-            content_image = self.transform_content(content_image)
-        if self.transform_style is not None:
-            style_image = self.transform_style(style_image)
-        return {'content_image': content_image, 'style_image': style_image}
+        return image if transform is None else transform(image)
+
+    def __getitem__(self, idx) -> Dict:
+        pair = {'content_image': (self.content_urls[idx], self.transform_content),
+                'style_image': (self.style_urls[idx], self.transform_style)}
+        if self.url_only:       # the eval loader: paths only (src/data/dataloader.py:56-58)
+            return {key: url for key, (url, _) in pair.items()}
+        return {key: self._decode(url, transform) for key, (url, transform) in pair.items()}
 
 
 class ShardedRandomSampler(Sampler):

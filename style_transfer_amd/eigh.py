@@ -28,6 +28,19 @@ _EVECT_ORIGINAL, _FILL_LOWER = 211, 122       # rocblas_evect_original, rocblas_
 _rs = _rb = None
 _handles: Dict[Tuple[int, int], c_void_p] = {}
 _pending: List[torch.Tensor] = []
+_FOLD_AT = 1024     # pending status tensors are folded into ONE device-side maximum at this count (nothing is dropped)
+
+
+def _keep(pending: List[torch.Tensor], status: torch.Tensor) -> None:
+    """Queue a per-call status tensor for check().  A long epoch (steps x groups) must neither grow the list without
+    bound nor lose entries: at _FOLD_AT entries the list collapses into one 1-element maximum, on the device, with no
+    host synchronisation (status values are >= 0 in both solvers' conventions after abs())."""
+    pending.append(status)
+    if len(pending) >= _FOLD_AT and not torch.cuda.is_current_stream_capturing():
+        by_dev: Dict[torch.device, List[torch.Tensor]] = {}
+        for t in pending:
+            by_dev.setdefault(t.device, []).append(t.abs().max().reshape(1))
+        pending[:] = [torch.cat(v).max().reshape(1) for v in by_dev.values()]
 
 
 def _load():
@@ -64,8 +77,8 @@ _small_pending: List[torch.Tensor] = []
 
 
 def syevj_small(a: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """The same for C <= 128 (even): the hand-written LDS-resident Jacobi kernel (csrc/eigh.hip), one workgroup per
-    matrix, ONE launch instead of rocSOLVER's hundreds."""
+    """The same through the hand-written LDS-resident Jacobi kernel (csrc/eigh.hip; any even C <= 128, routed here by
+    ``syevd`` for C <= SMALL_MAX = 64), one workgroup per matrix, ONE launch instead of rocSOLVER's hundreds."""
     lib = _lib.load()
     b, c, _ = (int(v) for v in a.shape)
     a = a.detach().contiguous()
@@ -75,15 +88,14 @@ def syevj_small(a: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     _lib.check(lib.st_syevj_small_batched(_lib.dev_ptr(a, "a"), _lib.dev_ptr(w, "w"), _lib.dev_ptr(v, "v"),
                                           _lib.dev_ptr(sweeps, "sweeps", torch.int32), b, c, MAX_SWEEPS,
                                           _lib.stream_ptr()), "st_syevj_small_batched")
-    if len(_small_pending) < 4096:
-        _small_pending.append(sweeps)
+    _keep(_small_pending, sweeps)
     return w, v
 
 
 def syevd(a: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Eigenvalues (ascending) [B, C] and eigenvectors V [B, C, C] (columns) of the symmetric matrices ``a``
-    [B, C, C], on torch's current stream, without any host synchronisation.  C <= 128: ``syevj_small``; larger:
-    rocSOLVER's syevd."""
+    [B, C, C], on torch's current stream, without any host synchronisation.  Even C <= SMALL_MAX (64):
+    ``syevj_small``; larger: rocSOLVER's syevd."""
     assert a.dim() == 3 and a.shape[1] == a.shape[2], f"expected [B, C, C], got {tuple(a.shape)}"
     b, c, _ = (int(v) for v in a.shape)
     if c % 2 == 0 and 2 <= c <= SMALL_MAX:
@@ -98,8 +110,7 @@ def syevd(a: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
                                              _lib.dev_ptr(e, "e"), c, _lib.dev_ptr(info, "info", torch.int32), b)
     if rc != 0:
         raise _lib.StHipError(f"rocsolver_ssyevd_strided_batched returned status {rc}")
-    if len(_pending) < 4096:
-        _pending.append(info)
+    _keep(_pending, info)
     # column-major output: the buffer read row-major holds V^T (rows = eigenvectors)
     return w, work.transpose(-1, -2)
 
@@ -110,13 +121,14 @@ def check() -> None:
     global _pending, _small_pending
     if _small_pending:
         sw, _small_pending = _small_pending, []
-        worst = int(torch.stack([s.max() for s in sw]).max())
-        if worst >= MAX_SWEEPS:
-            raise _lib.StHipError(f"linalg.eigh (Jacobi, C <= 128): no convergence within {MAX_SWEEPS} sweeps")
+        # the kernel reports the sweeps it used, or MAX_SWEEPS + 1 when it ran out without a rotation-free sweep
+        worst = max(int(s.max()) for s in sw)
+        if worst > MAX_SWEEPS:
+            raise _lib.StHipError(f"linalg.eigh (Jacobi, C <= {SMALL_MAX}): no convergence within {MAX_SWEEPS} sweeps")
     if not _pending:
         return
     infos, _pending = _pending, []
-    bad = int(torch.stack([i.abs().max() for i in infos]).max())
+    bad = max(int(i.abs().max()) for i in infos)
     if bad != 0:
         raise _lib.StHipError(f"linalg.eigh: the algorithm failed to converge ({bad} off-diagonal elements of an "
                               "intermediate tridiagonal form did not converge to zero)")

@@ -386,10 +386,17 @@ class VincentStyleLoss(nn.Module):
     #: against the reference's golden vectors).  No gradient flows through this side (style image only).
     #: The iteration is used only when the layer has more pixels than channels (H*W > C: every BASELINE config; a
     #: covariance of fewer samples than channels is rank-deficient by construction, and on an exactly singular input
-    #: the iteration's null directions are decided by rounding noise) -- otherwise the eigh route runs.  16
-    #: iterations: eigen-directions down to 1e-6 of the norm have converged, and a rounding-NEGATIVE eigenvalue of
-    #: the PSD input (|.| <= 1e-6 of the norm in fp32) cannot leave the iteration's basin within that many steps.
-    STYLE_ROOT = "newton-schulz"
+    #: the iteration's null directions are decided by rounding noise) -- otherwise the eigh route runs.
+    #: Convergence, stated exactly: a normalised eigenvalue p << 1 grows by (3 - p)^2 / 4 ~ 2.25 per iteration, so
+    #: after 16 iterations directions down to ~1e-5 of the (Frobenius) norm have converged; one at 1e-6 has reached
+    #: ~0.66 sqrt(lambda), i.e. its part of the root is 3e-4 of the root's norm off (the fp32 eigh route: ~5e-5 there),
+    #: and such a direction carries ~1e-6 of var_overlap.  A rounding-NEGATIVE eigenvalue of the PSD input at -1e-7 of
+    #: the norm (what fp32 covariance rounding produces) has grown to -0.04 after 16 iterations and contributes
+    #: -7e-5 of the norm to the root; at -1e-6 it would leave the basin two iterations later -- hence exactly 16, and
+    #: tests/test_gpu_eigh.py::test_style_root_routes_on_ill_conditioned_covariance pins both routes against float64
+    #: on a decaying spectrum with exact-zero rows (dead post-ReLU channels), var_overlap included.
+    #: ST_STYLE_ROOT=eigh|newton-schulz overrides the default for A/B runs.
+    STYLE_ROOT = os.environ.get("ST_STYLE_ROOT", "newton-schulz")
     NS_ITERS = 16
 
     @classmethod

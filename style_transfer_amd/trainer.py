@@ -633,7 +633,11 @@ class Trainer:
         """zero_grad (one memset of the flat bucket) + the forward up to the per-rank Hellinger sums.
         ``prefetch``: the NEXT batch (content, style), see optimize_step."""
         bucket.zero()
-        step.decoder._packed.direct_grads = True       # weight gradients are written straight into the bucket
+        # Weight gradients are written straight into the bucket -- an OVERWRITE, valid for exactly one decoder backward
+        # per zeroed bucket.  The flag is therefore scoped to this step: set here, cleared by step_backward, so any
+        # other backward through this decoder (a caller accumulating over several backwards, the decoder used twice
+        # in one graph) goes through autograd's accumulating path.
+        step.decoder._packed.direct_grads = True
         front = self._take_front(content_imgs, style_imgs)
         hook = None
         if prefetch is not None and hasattr(step.style_loss, "prefetch_stream"):
@@ -675,7 +679,10 @@ class Trainer:
         """Rest of compute_loss from the batch-wide q, then backward into the bucket (trainer.py:472)."""
         q = _InjectReducedQ.apply(partials[3], q_sum, self.world_size) if self.dp_active else partials[3]
         losses = step.combine(partials, q, global_batch)
-        losses[4].backward()
+        try:
+            losses[4].backward()
+        finally:
+            step.decoder._packed.direct_grads = False
         return losses
 
     def step_update(self, step: StyleTransferStep, optimizer, bucket: GradBucket):

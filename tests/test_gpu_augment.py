@@ -1,7 +1,8 @@
 """GPU-side augmentation (csrc/augment.hip, gpu_augment.py) against the CPU restatement of the reference's
 post-ToTensor transforms (transforms.py; src/train.py:116-135, src/utils/custom_transform.py:9-46) on identical,
 explicit per-image parameters.  PARITY UNPINNED against torchvision itself (0.15.1 is not installed here): the CPU
-restatement follows its documented behaviour; the two custom transforms are pinned by the reference's source."""
+restatement follows its documented behaviour; the two custom transforms are pinned by vectors generated from the
+reference's own module (tests/golden/transforms.npz, oracle/gen_golden.py --only transforms)."""
 import math
 
 import numpy as np
@@ -107,6 +108,47 @@ def test_gaussian_noise_matches_the_uint8_round_trip(shape):
         assert (d > 1e-6).float().mean().item() < 0.02
         levels = got[i] * 255
         assert (levels - levels.round()).abs().max().item() < 1e-3      # every value is a uint8 level
+
+
+def _golden_transforms():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms.npz"))
+
+
+def test_custom_transforms_match_reference_generated_vectors():
+    """The two transforms the reference wrote itself (src/utils/custom_transform.py:9-46), HIP kernels against vectors
+    produced by the reference's own module (oracle/gen_golden.py --only transforms): RGBToGrayscaleStacked outputs and
+    the uint8 array AddGaussianNoise hands to ToTensor, for the numpy RNG state the fixture names."""
+    gold = _golden_transforms()
+    for k in ("a", "b"):
+        x = torch.from_numpy(gold[f"img_{k}"])
+        _, h, w = x.shape
+        xd, yd = x.unsqueeze(0).to(DEV), torch.empty(1, 3, h, w, device=DEV)
+        call("st_aug_gray_stack", P(xd), P(yd), 1, h * w)
+        torch.testing.assert_close(yd[0].cpu(), torch.from_numpy(gold[f"gray_on_{k}"]), rtol=0, atol=2e-7)
+    seen = 0
+    for key, seed, mean, lo, hi, p in gold["noise_cases"]:
+        k, seed = chr(int(key)), int(seed)
+        if not bool(gold[f"noise_{k}_{seed}_applied"]):
+            continue
+        x = torch.from_numpy(gold[f"img_{k}"]).reshape(3, *gold[f"img_{k}"].shape[-2:])
+        _, h, w = x.shape
+        np.random.seed(seed)                       # the reference's draw order: gate, sigma, field (:16, :22, :23)
+        assert np.random.rand() < p
+        sigma = np.random.uniform(lo, hi)
+        field = np.random.normal(mean, sigma, (h, w, 3))
+        nd = torch.from_numpy(field).permute(2, 0, 1).float().unsqueeze(0).contiguous().to(DEV)
+        xd, yd, ws = x.unsqueeze(0).to(DEV), torch.empty(1, 3, h, w, device=DEV), torch.empty(2, device=DEV)
+        sd = torch.tensor([sigma], dtype=torch.float32, device=DEV)
+        call("st_aug_gaussian_noise", P(xd), P(nd), P(sd), P(yd), P(ws), 1, 3 * h * w)
+        got = (yd[0].cpu() * 255).round().permute(1, 2, 0).numpy().astype(np.int64)
+        want = gold[f"noise_{k}_{seed}_u8"].astype(np.int64)
+        d = np.abs(got - want)
+        # the reference interpolates in float64 (np.interp), the kernel in fp32 on an fp32 copy of the field:
+        # truncation to uint8 can land one level apart on a few values
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (k, seed, d.max(), (d > 0).mean())
+        seen += 1
+    assert seen >= 5
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 64), (3, 37, 53), (2, 2, 9), (8, 256, 256)])

@@ -59,6 +59,58 @@ def test_eigvalsh_backward_matches_torch_autograd(c):
     assert float((g - ref).norm() / ref.norm()) < 1e-3      # fp32 eigenvectors of an ill-conditioned matrix
 
 
+@pytest.mark.parametrize("c,n", [(64, 4096), (256, 1024), (512, 1024)])
+def test_style_root_routes_on_ill_conditioned_covariance(c, n, monkeypatch):
+    """cov_stl^(1/2) by Newton-Schulz (the default) and by eigh (the reference's route, losses.py:69-72) against
+    float64 on what post-ReLU VGG features look like and a well-conditioned randn matrix does not: channel scales
+    decaying over 3.5 decades (variances over 7), every eighth channel dead (an exact-zero row and column), n barely
+    above C at the 512-channel layer.  Checked: the root itself, tr_cov_stl, and the layer distance
+    tr_stl + tr_syn - 2 var_overlap of losses.py:73-80 with a stylised-side covariance of the same kind."""
+    import warnings
+    from style_transfer_amd import eigh
+    from style_transfer_amd.losses import VincentStyleLoss
+    g = torch.Generator().manual_seed(1000 + c)
+
+    def feats(offset, gain):
+        x = torch.relu(torch.randn(2, c, n, generator=g) + offset) * gain
+        x = x * torch.logspace(0, -3.5, c).view(1, c, 1)
+        x[:, ::8] = 0.0
+        return x
+    xs, xg = feats(0.3, 1.0), feats(0.0, 1.4)           # different statistics: the distance is not a small difference
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vin = VincentStyleLoss()
+
+    def moments64(x):
+        xc = x.double() - x.double().mean(-1, keepdim=True)
+        return xc @ xc.transpose(-1, -2)
+    cs64, cg64 = moments64(xs), moments64(xg)
+    lam, vec = torch.linalg.eigh(cs64)
+    root64 = (vec * lam.clip(0).sqrt().unsqueeze(-2)) @ vec.transpose(-1, -2)
+    tr64 = lam.clip(0).sum(-1, keepdim=True)
+    prod = root64 @ cg64 @ root64
+    dist64 = tr64 + torch.linalg.eigvalsh(cg64).clip(0).sum(-1, keepdim=True) \
+        - 2 * torch.linalg.eigvalsh(0.5 * (prod + prod.transpose(-1, -2))).clip(0.1).sqrt().sum(-1, keepdim=True)
+    _, cov_s = vin.calc_2_moments(xs.view(2, c, n, 1).cuda())
+    _, cov_g = vin.calc_2_moments(xg.view(2, c, n, 1).cuda())
+    report = {}
+    for route in ("newton-schulz", "eigh"):
+        monkeypatch.setattr(VincentStyleLoss, "STYLE_ROOT", route)
+        root, tr = VincentStyleLoss._style_side(cov_s, n_pixels=n)
+        dist = VincentStyleLoss._synth_side(root, tr, cov_g)
+        e_root = float((root.cpu().double() - root64).norm() / root64.norm())
+        e_tr = float(((tr.cpu().double() - tr64).abs() / tr64).max())
+        e_dist = float(((dist.cpu().double() - dist64).abs() / dist64.abs()).max())
+        report[route] = (e_root, e_tr, e_dist)
+        assert torch.isfinite(root).all()
+        assert e_root < 2e-3 and e_tr < 1e-5, (route, report)
+        assert e_dist < 1e-3, (route, report)             # the task's fp32 bar, on the layer's distance
+    eigh.check()
+    print(f"\n[C={c}, n={n}] (root, trace, distance) relative to float64: {report}")
+    # the iteration is as good as the reference's route where it matters: the distance
+    assert report["newton-schulz"][2] < max(3 * report["eigh"][2], 2e-4), report
+
+
 def test_small_eigh_timing_report():
     """Not a pass/fail bar: prints what the hand-written kernel costs next to rocSOLVER at the style-layer shapes."""
     import time

@@ -33,6 +33,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # executed work next to the algorithmic figure (the sub-pixel upsample layers perform 16/36 of their multiply-adds)
+    assert "16 multiply-adds per source pixel" in r["method"]
+    cfg = d["config"]
+    assert 0 < cfg["executed_gflop_per_image"] < cfg["gflop_per_image"]
+    assert 0 < d["model_tflops_executed"] < d["model_tflops"]
+    assert abs(d["model_tflops_executed"] / d["model_tflops"] - cfg["executed_gflop_per_image"] / cfg["gflop_per_image"]) < 2e-2
+    assert 0 < d["hires"]["model_tflops_executed"] < d["hires"]["model_tflops"]
     assert d["train"]["value"] > 0 and d["bf16"]["inference"]["value"] > 0 and d["bf16x3"]["inference"]["value"] > 0
     for name, bound, unit in (("roofline_hist", "hbm", "GB/s"), ("roofline_tv", "hbm", "GB/s"), ("roofline_cov", "mfma", "TFLOP/s")):
         o = d[name]

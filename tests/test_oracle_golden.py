@@ -195,3 +195,31 @@ def test_hist_block_options_gradient_matches_the_reference(golden_dir):
     (R.rgbuv_hist(x, insz=128, h=32, method="inverse-quadratic", green_only=True, resizing="sampling")
      * torch.from_numpy(g["grad_w"])).sum().backward()
     torch.testing.assert_close(x.grad, torch.from_numpy(g["grad_dbig"]), rtol=1e-3, atol=1e-8)
+
+
+def test_custom_transforms_against_reference_vectors():
+    """style_transfer_amd/transforms.py's restatement of the reference's two own transforms
+    (src/utils/custom_transform.py:9-46) against vectors generated from the reference module itself
+    (oracle/gen_golden.py --only transforms; the torchvision ops stay parity-unpinned)."""
+    import os
+    from style_transfer_amd import transforms as T
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms.npz"))
+    for k in ("a", "b"):
+        x = torch.from_numpy(gold[f"img_{k}"])
+        np.testing.assert_allclose(T.RGBToGrayscaleStacked(True)(x.clone()).numpy(), gold[f"gray_on_{k}"], rtol=0, atol=6e-8)
+        assert np.array_equal(T.RGBToGrayscaleStacked(False)(x.clone()).numpy(), gold[f"gray_off_{k}"])
+        # the blue weight is 0.144 as the reference writes it (:41), not the usual 0.114
+        assert abs(float(T.RGBToGrayscaleStacked(True)(torch.tensor([0., 0., 1.]).view(3, 1, 1))[0]) - 0.144) < 1e-7
+    applied = 0
+    for key, seed, mean, lo, hi, p in gold["noise_cases"]:
+        k, seed = chr(int(key)), int(seed)
+        x = torch.from_numpy(gold[f"img_{k}"])
+        np.random.seed(seed)                       # same numpy stream, same draw order as the reference (:16-23)
+        out = T.AddGaussianNoise(mean=mean, sigma_range=(lo, hi), p=p)(x.clone())
+        if bool(gold[f"noise_{k}_{seed}_applied"]):
+            u8 = (out * 255).round().permute(1, 2, 0).numpy().astype(np.uint8)
+            assert np.array_equal(u8, gold[f"noise_{k}_{seed}_u8"]), (k, seed)      # bit-exact uint8 levels
+            applied += 1
+        else:
+            assert torch.equal(out, x)
+    assert applied >= 5
