@@ -155,18 +155,25 @@ int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_packed, const 
 int st_conv3x3_dgrad_bf16_g8(const void* dy, int dy_g8, const void* w_packed_t, void* dx, int dx_g8,
                              const void* dx_gate_g8, int n, int cout, int h, int w, int cin, st_stream_t stream);
 /* bf16 mode, data gradient of a REPLICATE-padded decoder layer (generator.py:85-130; loss.backward() of
- * trainer.py:472) inside a G8 chain.  dy [n][cout][h][w]: fp32 NCHW or (dy_g8) G8, already gated.  The padded-domain
- * result goes to `workspace` (st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, ST_PAD_REPLICATE)) and is folded onto the
- * source pixels [n][cin][h >> up][w >> up] (adjoint of the pad and of the nearest x2 upsample), zeroed where dx_gate
- * -- the layer's input activation, fp32 NCHW or (dx_gate_g8) G8, may be NULL -- is <= 0, and written in every form
- * requested (each may be NULL): dx_f32 fp32 NCHW; dx_g8 G8 (operand of the next st_conv3x3_dgrad_bf16_g8_chain);
- * dx_g16 bf16 [n][cin][h][w] and bias_slabs [n * st_conv3x3_dgrad_fold8_bias_slabs(h, w, up)][cin] fp32 partial
- * sums (operands of st_conv3x3_wgrad_bf16_pre of the layer below).  Needs cin % 8 == 0 and (w >> up) % 4 == 0.
- * Same fp32 values as st_conv3x3_dgrad_bf16 with dx_gate. */
+ * trainer.py:472) inside a G8 chain.  dy [n][cout][h][w]: fp32 NCHW or (dy_g8) G8, already gated.  The result --
+ * the adjoint of the edge-replicate pad (generator.py:19-39) and of the nearest x2 upsample applied to the
+ * padded-domain data gradient, on the source pixels [n][cin][h >> up][w >> up], zeroed where dx_gate (the layer's
+ * input activation, fp32 NCHW or (dx_gate_g8) G8, may be NULL) is <= 0 -- is written in every form requested (each
+ * may be NULL): dx_f32 fp32 NCHW; dx_g8 G8 (operand of the next st_conv3x3_dgrad_bf16_g8_chain); dx_g16 bf16
+ * [n][cin][h][w] and bias_slabs [st_conv3x3_dgrad_chain_bias_slabs(n, cin, h, w, up)][cin] fp32 partial sums
+ * (operands of st_conv3x3_wgrad_bf16_pre of the layer below; every row is written).  Two forms, same fp32 values per
+ * element: (1) with a G8 result and no fp32 one (every layer but the bottom of the chain), more than 32 channels and
+ * an even (x4 under the upsample) h, w: the zero-padded conv on the UNPADDED grid with fold / gate / hand-over forms
+ * in its epilogue, then two small launches that redo the border source pixels from the padded-domain values of the
+ * ring (csrc/dgrad_band.hip; `workspace` holds those); (2) otherwise the padded-domain result goes to `workspace`
+ * and a second pass folds it.  `workspace`: st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, ST_PAD_REPLICATE) for
+ * both.  Needs cin % 8 == 0 and (w >> up) % 4 == 0.  Same fp32 values as st_conv3x3_dgrad_bf16 with dx_gate. */
 int st_conv3x3_dgrad_bf16_g8_chain(const void* dy, int dy_g8, const void* w_packed_t, float* workspace,
                                    const void* dx_gate, int dx_gate_g8, float* dx_f32, void* dx_g8, void* dx_g16,
                                    float* bias_slabs, int n, int cout, int h, int w, int cin, int upsample2x,
                                    st_stream_t stream);
+int st_conv3x3_dgrad_chain_bias_slabs(int n, int cin, int h, int w, int upsample2x);
+/* rows per image written by form (2) alone (kept for callers of the round-2 interface) */
 int st_conv3x3_dgrad_fold8_bias_slabs(int h, int w, int upsample2x);
 /* Weight gradient of a decoder layer whose gated output gradient arrives READY from the launch above: g16 bf16
  * [n][cout][H][W] and bias_slabs [n_bias_slabs][cout] (summed in a fixed order into dbias; dbias may be NULL); x is

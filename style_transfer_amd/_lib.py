@@ -39,6 +39,7 @@ SIGNATURES = {
     "st_conv3x3_dgrad_bf16_g8_chain": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_dgrad_fold8_bias_slabs": (c_int, [c_int, c_int, c_int]),
+    "st_conv3x3_dgrad_chain_bias_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_wgrad_bf16_pre_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_wgrad_bf16_pre": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

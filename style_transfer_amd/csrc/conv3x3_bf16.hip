@@ -76,7 +76,38 @@ struct ConvParams {
   // G8 output only (st_conv3x3_dgrad_bf16_g8): a G8 tensor of the OUTPUT's shape; the result is stored as 0 where
   // it is <= 0 -- the ReLU gate of the layer that produced this kernel's output tensor's forward twin
   const u32x4* ogate = nullptr;
+  // EPI kernels only (decoder chain data gradient with the pad / upsample adjoint and the hand-over forms in the
+  // epilogue, st_conv3x3_dgrad_bf16_g8_chain): y = the G8 result [n][cout/8][hs][ws][8] on the SOURCE grid
+  // (hs, ws = Ho, Wo or their halves under the upsample); the gate is the layer's input activation on that grid
+  const u32x4* egate_g8 = nullptr;   // G8, or
+  const float* egate_f32 = nullptr;  // fp32 NCHW, or neither
+  unsigned short* g16 = nullptr;     // optional: the same result as pixel-major bf16 [n][cout][hs][ws]
+  float* bslabs = nullptr;           // optional: [n * tiles per image * WP][cout] per-wave sums of the result over its
+                                     // INTERIOR source pixels (the border ring is summed by the band kernels)
 };
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// lane exchanges / reductions on the DPP path (no LDS traffic)
+__device__ __forceinline__ float dpp_xor1(float v) {      // quad_perm [1, 0, 3, 2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {      // quad_perm [2, 3, 0, 1]
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+// sum over the 32 lanes of each wave half, fixed order: inclusive scan inside the 16-lane rows (row_shr 1, 2, 4, 8,
+// zeros shifted in), then lane 15 of row 0 / 2 is added to row 1 / 3 (row_bcast:15): lanes 31 and 63 hold the totals
+__device__ __forceinline__ float half_wave_sum_to_lane31(float v) {
+#define ST_DPP_ADD(ctrl_, rmask_)                                                                          \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, rmask_, 0xF, true))
+  ST_DPP_ADD(0x111, 0xF);
+  ST_DPP_ADD(0x112, 0xF);
+  ST_DPP_ADD(0x114, 0xF);
+  ST_DPP_ADD(0x118, 0xF);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+#undef ST_DPP_ADD
+  return v;
+}
 
 // 8 bf16 lanes of `v` kept where the same lane of `g` is > 0 (bit test: 0x0001 .. 0x7f80 = positive, incl. +inf)
 __device__ __forceinline__ u32x4 gate_g8(u32x4 v, u32x4 g) {
@@ -126,11 +157,20 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
 // fp32-activation form) and writes 16 B per pixel and channel group.  With SPLIT (bf16x3) the layout is the hi/lo
 // pair form bf16 [n][c/8][2][h][w][8] (part 0 = bf16(v), part 1 = bf16(v - hi): the same split the staging of an
 // fp32 activation performs, done once by the producer): as many bytes as fp32, but both images arrive by LDS-DMA.
+//
+// EPI != 0 (with YG): the data gradient of a replicate-padded decoder layer inside the G8 chain, computed on the
+// UNPADDED grid as a zero-padded conv (exactly the padded-domain GEMM's accumulators at the same pixels) with the
+// rest of the old padded workspace -> dgrad_fold8_kernel round trip in the epilogue: [(EPI & 3) == 2: the 2 x 2 sum of
+// the nearest-upsample adjoint, row pairs in one wave, column pairs by DPP] -> gate by the input activation (G8, or
+// fp32 NCHW when EPI & 4) -> the G8 form, the pixel-major bf16 form and per-wave bias partial sums.  Source pixels on
+// the image border also receive the padded ring's gradient: those are recomputed and OVERWRITTEN by the band kernels
+// (csrc/dgrad_band.hip) that run after this launch, and are left out of the bias sums here.
 template <int MT, int NT, int WM, int WP, bool GATE, bool TAIL, bool SPLIT, bool PIPE, bool XG = false,
-          bool YG = false>
+          bool YG = false, int EPI = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p) {
   using C = Cfg<MT, NT, WM, WP, SPLIT>;
   static_assert(WM * WP == 8, "eight waves per block");
+  static_assert(EPI == 0 || (YG && !SPLIT && !GATE && NT % 4 == 0), "chain epilogue: G8 output, plain bf16");
   static_assert(!XG || (!GATE && !TAIL), "G8 input: plain forward form only");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   u32x4* Ws = smem16;                     // 2 x [part][tap][half][BM]   (filled by LDS-DMA)
@@ -561,7 +601,160 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   // becomes store-ISSUE-bound.  Each wave therefore transposes a tile through a private 4 KB LDS
   // patch (the staging buffers are free after the last barrier) and writes 16 B per lane: 8 lanes
   // cover one 128-B row segment, a wave instruction writes 8 channel rows.
-  if constexpr (YG) {
+  if constexpr (EPI != 0) {
+    constexpr bool UPF = (EPI & 3) == 2;
+    constexpr bool GF32 = (EPI & 4) != 0;                   // the gate is fp32 NCHW (else G8, or none)
+    unsigned* patch = reinterpret_cast<unsigned*>(smem16 + (PERSIST ? 2 * C::W_UNITS + 2 * C::X_UNITS : 0) +
+                                                  wave * 128);
+    const u32x4* patch16 = reinterpret_cast<const u32x4*>(patch);
+    u32x4* yg = reinterpret_cast<u32x4*>(p.y);
+    const int cgroups = p.cout >> 3;
+    const int hs = UPF ? p.Ho >> 1 : p.Ho, ws = UPF ? p.Wo >> 1 : p.Wo;
+    const size_t plane_s = size_t(hs) * ws;
+    const int sx = UPF ? ((x0 + li) >> 1) : x0 + li;
+    const int sxc = min(sx, ws - 1);                        // clamped twin for the (unconditional) gate loads
+    const bool lane_on = !UPF || !(li & 1);                 // under the upsample the even lanes carry the 16 source pixels
+    const bool odd = UPF ? (li & 2) != 0 : (li & 1) != 0;   // second pixel of a pixel pair (pixel-major bf16 stores)
+    constexpr int NROW = UPF ? NT / 2 : NT;                // output rows of this wave
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int cbase = m0 + wm * (MT * 32) + mt * 32;
+      float bsum[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum[r] = 0.f;
+      // The gate values of several rows are requested before the first one is used (with one request per row in flight
+      // the epilogue of the wide, shallow layers -- 64 channels at 512 x 512, K = 27 or 576 -- ran at the latency of
+      // its loads).  The loads are UNCONDITIONAL on clamped addresses (rows / columns / channels past the end read a
+      // valid neighbour whose result is never stored): a predicated load puts a wait in front of the next one.
+      constexpr int GROWS = GF32 ? 2 : NROW;               // fp32 gate: two rows at a time (32 registers)
+      u32x2 gq[GF32 ? 1 : NROW][4];
+      float gf[GF32 ? GROWS : 1][16];
+      auto load_gates = [&](int first) {
+        if constexpr (GF32) {
+#pragma unroll
+          for (int i = 0; i < GROWS; ++i) {
+            const int row = min(first + i, NROW - 1);
+            const int sy = min(UPF ? (y0 + wp * NT + 2 * row) >> 1 : y0 + wp * NT + row, hs - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = min(cbase + (r & 3) + 8 * (r >> 2) + 4 * lh, p.cout - 1);
+              gf[i][r] = __builtin_nontemporal_load(p.egate_f32 + (size_t(b) * p.cout + co) * plane_s + size_t(sy) * ws + sxc);
+            }
+          }
+        } else if (p.egate_g8) {
+#pragma unroll
+          for (int i = 0; i < NROW; ++i) {
+            const int sy = min(UPF ? (y0 + wp * NT + 2 * i) >> 1 : y0 + wp * NT + i, hs - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cg = min((cbase >> 3) + q, cgroups - 1);
+              gq[i][q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned*>(
+                             p.egate_g8 + (size_t(b) * cgroups + cg) * plane_s + size_t(sy) * ws + sxc) + lh * 2);
+            }
+          }
+        }
+      };
+      if constexpr (!GF32) load_gates(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt += (UPF ? 2 : 1)) {
+        const int irow = UPF ? nt / 2 : nt;
+        if constexpr (GF32) {
+          if (irow % GROWS == 0 && !(p.ablate & 16)) load_gates(irow);
+        }
+        const int yy = y0 + wp * NT + nt;
+        const int sy = UPF ? yy >> 1 : yy;
+        const bool ok = lane_on && sy < hs && sx < ws;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (UPF) {      // (p[2i][2j] + p[2i][2j+1]) + (p[2i+1][2j] + p[2i+1][2j+1]): dgrad_fold8_kernel's order
+            float a = acc[mt][nt][r], c2 = acc[mt][nt + 1 < NT ? nt + 1 : nt][r];
+            a += dpp_xor1(a);
+            c2 += dpp_xor1(c2);
+            v[r] = a + c2;
+          } else {
+            v[r] = acc[mt][nt][r] + 0.f;
+          }
+        }
+        if constexpr (GF32) {
+          if (!(p.ablate & 16)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = gf[irow % GROWS][r] > 0.f ? v[r] : 0.f;
+          }
+        } else if (p.egate_g8) {      // keep where the bf16 input activation is > 0 (0x0001 .. 0x7f80)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned hb = (j & 1) ? (gq[irow][q][j >> 1] >> 16) : (gq[irow][q][j >> 1] & 0xffffu);
+              if (!((hb - 1u) < 0x7f80u)) v[q * 4 + j] = 0.f;
+            }
+        }
+        const bool inner = ok && sy > 0 && sy < hs - 1 && sx > 0 && sx < ws - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bsum[r] += inner ? v[r] : 0.f;
+        // G8: [pixel][4 groups][8 ch] through the wave's 2 KB patch, 16 B per lane and pixel
+        const int slot = UPF ? (li >> 1) : li;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bf16x4 h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[q * 4 + j];
+          if (lane_on) {
+            const u32x2 hv = __builtin_bit_cast(u32x2, h);
+            patch[(slot * 4 + q) * 4 + lh * 2 + 0] = hv[0];
+            patch[(slot * 4 + q) * 4 + lh * 2 + 1] = hv[1];
+          }
+        }
+        asm volatile("" ::: "memory");
+        if (!UPF) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int q = k * 2 + lh;
+            const int cg = (cbase >> 3) + q;
+            const u32x4 v4 = patch16[li * 4 + q];
+            if (cg < cgroups && sy < hs && sx < ws && !(p.ablate & 32))
+              yg[(size_t(b) * cgroups + cg) * plane_s + size_t(sy) * ws + sx] = v4;
+          }
+        } else {
+          const int q = lane >> 4, px = lane & 15;
+          const int cg = (cbase >> 3) + q;
+          const u32x4 v4 = patch16[px * 4 + q];
+          if (cg < cgroups && sy < hs && (x0 >> 1) + px < ws)
+            yg[(size_t(b) * cgroups + cg) * plane_s + size_t(sy) * ws + (x0 >> 1) + px] = v4;
+        }
+        asm volatile("" ::: "memory");
+        // pixel-major bf16: lanes exchange one register of each pair so that a lane stores two neighbouring pixels
+        // of ONE channel (4 B); 16 lanes cover a 64-B row segment (32 B under the upsample)
+        if (p.g16) {
+          const int px0 = UPF ? (sx & ~1) : (x0 + (li & ~1));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float send = odd ? v[2 * k] : v[2 * k + 1];
+            const float recv = UPF ? dpp_xor2(send) : dpp_xor1(send);
+            bf16x2 h2;
+            h2[0] = (__bf16)(odd ? recv : v[2 * k]);
+            h2[1] = (__bf16)(odd ? v[2 * k + 1] : recv);
+            const int r = 2 * k + (odd ? 1 : 0);
+            const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (ok && co < p.cout)
+              *reinterpret_cast<unsigned*>(p.g16 + (size_t(b) * p.cout + co) * plane_s + size_t(sy) * ws + px0) =
+                  __builtin_bit_cast(unsigned, h2);
+          }
+        }
+      }
+      if (p.bslabs) {
+        const int tile_img = (y0 / C::TH) * p.tiles_x + x0 / TW;
+        float* brow = p.bslabs + ((size_t(b) * p.tiles_x * p.tiles_y + tile_img) * WP + wp) * p.cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float t = half_wave_sum_to_lane31(bsum[r]);
+          const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (li == 31 && co < p.cout) brow[co] = t;
+        }
+      }
+    }
+  } else if constexpr (YG) {
     // G8 bf16 output: a wave turns each 32 ch x 32 px accumulator tile into [32 px][4 groups][8 ch] bf16 through a
     // private 2 KB LDS patch per image (lanes l and l+32 hold the two halves of a pixel's 8-channel group) and
     // stores 16 B per lane: 32 lanes cover 512 contiguous bytes of one channel group's row.  SPLIT: a second
@@ -856,6 +1049,46 @@ int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
   return st::check_launch("st_conv3x3_fwd_bf16_g8");
 }
 
+// Chain data gradient with the fused epilogue (EPI: see the kernel); xg: dy arrives as G8 (persistent form), else
+// fp32 NCHW (the 3-channel top layer: TAIL staging).
+template <int MT, int NT, int WM, int WP, int EPI>
+int launch_conv_chain(ConvParams& p, bool xg, hipStream_t stream) {
+  using C = Cfg<MT, NT, WM, WP, false>;
+  p.tiles_x = st::cdiv(p.Wo, TW);
+  p.tiles_y = st::cdiv(p.Ho, C::TH);
+  { const char* e = getenv("ST_BF16_ABLATE"); p.ablate = e ? atoi(e) : 0; }   // debug: 8 no g16, 16 no gate, 32 no G8, 64 no bias
+  if (p.ablate & 8) p.g16 = nullptr;
+  if (p.ablate & 16) p.egate_g8 = nullptr;
+  if (p.ablate & 64) p.bslabs = nullptr;
+  const long long ptiles = (long long)p.n * p.tiles_x * p.tiles_y;
+  p.ctiles = st::cdiv(p.cout, C::BM);
+  ST_REQUIRE(ptiles * p.ctiles <= 0x7fffffffLL, "st_conv3x3_dgrad_bf16_g8_chain: too many tiles (%lld)", ptiles * p.ctiles);
+  p.xcd_swizzle = (ptiles % 8 == 0) ? 1 : 0;
+  p.vec_store = 0;
+  p.ntiles = (int)(ptiles * p.ctiles);
+  if (xg) {
+    dim3 pgrid((unsigned)std::min<long long>(p.ntiles, 256));
+    ST_LAUNCH_DYN_LDS("st_conv3x3_dgrad_bf16_g8_chain",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, false, true, true, EPI>), pgrid,
+                      dim3(NTHREADS), C::LDS_BYTES + 8 * 128 * 16, stream, p);
+  } else if (p.cin % KC != 0) {
+    ST_LAUNCH_DYN_LDS("st_conv3x3_dgrad_bf16_g8_chain",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, true, false, false, false, true, EPI>),
+                      dim3((unsigned)p.ntiles), dim3(NTHREADS), C::LDS_BYTES, stream, p);
+  } else {
+    ST_LAUNCH_DYN_LDS("st_conv3x3_dgrad_bf16_g8_chain",
+                      (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, false, false, false, true, EPI>),
+                      dim3((unsigned)p.ntiles), dim3(NTHREADS), C::LDS_BYTES, stream, p);
+  }
+  return st::check_launch("st_conv3x3_dgrad_bf16_g8_chain");
+}
+
+// rows of the bias partial-sum buffer the fused chain epilogue writes per image: (pixel tiles) x (waves along y)
+inline int chain_main_slabs(int cin, int h, int w) {
+  const int th = cin > 64 ? 16 : 32, wpn = cin > 64 ? 4 : 8;
+  return st::cdiv(w, TW) * st::cdiv(h, th) * wpn;
+}
+
 template <bool GATE>
 int dispatch_conv(ConvParams& p, hipStream_t s, bool split = false) {
   // bf16x3: hi and lo images of both operands -> 64 ch x (16 rows x 32) is the tile that fits LDS
@@ -880,6 +1113,13 @@ int launch_dgrad_fold(const float* dxp, float* dx, const float* gate, int n, int
 int fold8_blocks_per_plane(int hs, int ws, int* iters_out);
 int launch_dgrad_fold8(const float* dxp, const float* gate_f32, const void* gate_g8, float* dx, void* g8, void* g16,
                        float* bias, int n, int c, int h, int w, int up, hipStream_t s);
+// csrc/dgrad_band.hip: the border ring of the chain data gradient (padded-domain values on the band of pixels the
+// border source pixels need, then their fold / gate / hand-over forms; overwrites the main launch's border pixels)
+size_t dgrad_band_scratch_bytes(int n, int c, int h, int w, int up);
+int dgrad_band_slabs(int h, int w, int up);
+int launch_dgrad_band(const void* dy, int dy_g8, const void* w_packed_t, float* scratch, const float* gate_f32,
+                      const void* gate_g8, float* dx_f32, void* g8, void* g16, float* bias, int n, int k, int c, int h,
+                      int w, int up, hipStream_t s);
 }  // namespace st
 
 extern "C" size_t st_conv3x3_packed_elems_bf16(int cout, int cin) {
@@ -1021,6 +1261,23 @@ extern "C" int st_conv3x3_dgrad_bf16_g8(const void* dy, int dy_g8, const void* w
                              stream, false, dx_gate_g8);
 }
 
+// The fused chain form (EPI kernels + band kernels) covers the decoder's training shapes: more than 32 channels (the
+// 64- / 128-channel tiles), pixel pairs whole (pixel-major bf16 stores), at least a 4 x 4 source grid so that the four
+// border sides are distinct.  ST_NO_FUSED_FOLD=1 keeps the padded workspace + dgrad_fold8_kernel path (A/B runs).
+static bool chain_fused_ok(int cin, int h, int w, int up) {
+  if (getenv("ST_NO_FUSED_FOLD") != nullptr) return false;      // read per call: tests flip it inside one process
+  const int hs = h >> up, ws = w >> up;
+  return cin > 32 && cin % 8 == 0 && (h & ((2 << up) - 1)) == 0 && (w & ((2 << up) - 1)) == 0 && hs >= 4 && ws >= 4;
+}
+
+extern "C" int st_conv3x3_dgrad_chain_bias_slabs(int n, int cin, int h, int w, int upsample2x) {
+  const int up = upsample2x ? 1 : 0;
+  if (n <= 0 || cin <= 0 || h <= 0 || w <= 0 || (w >> up) % 4 != 0) return 0;
+  const int fold = n * st::fold8_blocks_per_plane(h >> up, w >> up, nullptr);
+  if (!chain_fused_ok(cin, h, w, up)) return fold;
+  return std::max(fold, n * (chain_main_slabs(cin, h, w) + st::dgrad_band_slabs(h, w, up)));
+}
+
 // Data gradient of a REPLICATE-padded (decoder) layer inside a G8 chain: dy fp32 NCHW or G8 (already gated), the
 // padded-domain result goes to `workspace` (st_conv3x3_dgrad_workspace_bytes) and st::launch_dgrad_fold8 folds it,
 // applies the gate of the layer below and writes the requested forms (see include/st_hip.h).
@@ -1042,15 +1299,46 @@ extern "C" int st_conv3x3_dgrad_bf16_g8_chain(const void* dy, int dy_g8, const v
     ST_REQUIRE(reinterpret_cast<uintptr_t>(q) % 16 == 0, "st_conv3x3_dgrad_bf16_g8_chain: 16-byte aligned buffers expected");
   ST_REQUIRE((long long)(h + 2) * (w + 2) * 16 < (1LL << 31), "st_conv3x3_dgrad_bf16_g8_chain: plane too large");
   hipStream_t s = (hipStream_t)stream;
+  const int up = upsample2x ? 1 : 0;
   ConvParams p;
   p.x = (const float*)dy; p.gate = nullptr; p.wp = (const u32x4*)w_packed_t; p.bias = nullptr; p.y = workspace;
   p.n = n; p.cin = cout; p.hs = h; p.ws = w; p.cout = cin;
   p.up = 0; p.H = h; p.W = w;
-  p.Ho = h + 2; p.Wo = w + 2; p.shift = 1;
-  p.ldo = st::padded_row(w); p.pool = 0;
   p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
   p.nchunks = st::cdiv(cout, KC);
-  p.pad_zero = 1; p.relu = 0;
+  p.pad_zero = 1; p.relu = 0; p.pool = 0;
+  if (chain_fused_ok(cin, h, w, up) && dx_g8 && !dx_f32) {
+    // Fused form: the zero-padded conv on the unpadded grid with fold / gate / hand-over forms in its epilogue
+    // (interior source pixels are final), then the band kernels recompute the border source pixels from the
+    // padded-domain values of the ring and its neighbours and overwrite them.  No padded fp32 workspace round trip.
+    p.y = (float*)dx_g8; p.g16 = (unsigned short*)dx_g16; p.bslabs = bias_slabs;
+    p.egate_g8 = dx_gate_g8 ? (const u32x4*)dx_gate : nullptr;
+    p.egate_f32 = dx_gate_g8 ? nullptr : (const float*)dx_gate;
+    p.Ho = h; p.Wo = w; p.shift = 0; p.ldo = w;
+    int rc;
+    const bool xg = dy_g8 != 0;
+    if (p.egate_f32) {        // the top of the chain (64 <- 3 at full resolution): the one layer whose input is kept fp32
+      if (cin > 64) rc = up ? launch_conv_chain<2, 4, 2, 4, 6>(p, xg, s) : launch_conv_chain<2, 4, 2, 4, 5>(p, xg, s);
+      else rc = up ? launch_conv_chain<2, 4, 1, 8, 6>(p, xg, s) : launch_conv_chain<2, 4, 1, 8, 5>(p, xg, s);
+    } else {
+      if (cin > 64) rc = up ? launch_conv_chain<2, 4, 2, 4, 2>(p, xg, s) : launch_conv_chain<2, 4, 2, 4, 1>(p, xg, s);
+      else rc = up ? launch_conv_chain<2, 4, 1, 8, 2>(p, xg, s) : launch_conv_chain<2, 4, 1, 8, 1>(p, xg, s);
+    }
+    if (rc != ST_OK) return rc;
+    float* band_bias = bias_slabs ? bias_slabs + size_t(n) * chain_main_slabs(cin, h, w) * cin : nullptr;
+    if (bias_slabs) {     // rows of the (either-path) buffer beyond the ones written here read as zero
+      const int used = n * (chain_main_slabs(cin, h, w) + st::dgrad_band_slabs(h, w, up));
+      const int all = st_conv3x3_dgrad_chain_bias_slabs(n, cin, h, w, upsample2x);
+      if (all > used) {
+        hipError_t e = hipMemsetAsync(bias_slabs + size_t(used) * cin, 0, size_t(all - used) * cin * sizeof(float), s);
+        if (e != hipSuccess) return st::fail(ST_ERR_LAUNCH, "st_conv3x3_dgrad_bf16_g8_chain: memset: %s", hipGetErrorString(e));
+      }
+    }
+    return st::launch_dgrad_band(dy, dy_g8, w_packed_t, workspace, p.egate_f32, p.egate_g8, nullptr, dx_g8, dx_g16,
+                                 band_bias, n, cout, cin, h, w, up, s);
+  }
+  p.Ho = h + 2; p.Wo = w + 2; p.shift = 1;
+  p.ldo = st::padded_row(w);
   int rc;
   if (dy_g8) {
     if (cin > 64) rc = launch_conv_g8<2, 4, 2, 4>(p, true, false, s);
@@ -1060,8 +1348,16 @@ extern "C" int st_conv3x3_dgrad_bf16_g8_chain(const void* dy, int dy_g8, const v
     rc = dispatch_conv<false>(p, s, false);
   }
   if (rc != ST_OK) return rc;
+  if (bias_slabs) {       // the buffer is sized for either path: rows this path does not write must read as zero
+    const int mine = n * st::fold8_blocks_per_plane(h >> up, w >> up, nullptr);
+    const int all = st_conv3x3_dgrad_chain_bias_slabs(n, cin, h, w, upsample2x);
+    if (all > mine) {
+      hipError_t e = hipMemsetAsync(bias_slabs + size_t(mine) * cin, 0, size_t(all - mine) * cin * sizeof(float), s);
+      if (e != hipSuccess) return st::fail(ST_ERR_LAUNCH, "st_conv3x3_dgrad_bf16_g8_chain: memset: %s", hipGetErrorString(e));
+    }
+  }
   return st::launch_dgrad_fold8(workspace, dx_gate_g8 ? nullptr : (const float*)dx_gate, dx_gate_g8 ? dx_gate : nullptr,
-                                dx_f32, dx_g8, dx_g16, bias_slabs, n, cin, h, w, upsample2x ? 1 : 0, s);
+                                dx_f32, dx_g8, dx_g16, bias_slabs, n, cin, h, w, up, s);
 }
 
 extern "C" int st_conv3x3_dgrad_fold8_bias_slabs(int h, int w, int upsample2x) {

@@ -266,6 +266,28 @@ __global__ __launch_bounds__(64) void slab_reduce_wave_kernel(const float* __res
   if (threadIdx.x == 0) out[e] = s;
 }
 
+// Thousands of rows (the fused chain epilogue writes one per wave and pixel tile): first stage of a two-stage sum.
+// A block sums `rows_per_seg` consecutive rows for 16 consecutive elements -- thread = (element, one of 16 row lanes),
+// so a row contributes one full 64-B sector -- and writes one row of partial[seg][n]; the wave kernel sums those.
+__global__ __launch_bounds__(256) void slab_reduce_rows_kernel(const float* __restrict__ slabs,
+                                                              float* __restrict__ partial, int n, int nslabs,
+                                                              int rows_per_seg) {
+  __shared__ float red[16][17];
+  const int e = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4, seg = blockIdx.y;
+  const int k0 = seg * rows_per_seg, k1 = min(k0 + rows_per_seg, nslabs);
+  float s = 0.f;
+  if (e < n)
+    for (int k = k0 + rl; k < k1; k += 16) s += slabs[(size_t)k * n + e];
+  red[rl][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+    partial[(size_t)seg * n + e] = t;
+  }
+}
+
 // ================================================================================================
 // bf16 compute mode (BASELINE configs[3]): the same GEMM with bf16 operands and fp32 accumulation,
 // v_mfma_f32_32x32x16_bf16, K step = 16 consecutive pixels of one tile row.
@@ -1056,7 +1078,19 @@ extern "C" int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g1
   const long long nw = (long long)cout * cin * 9;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(nw, 256), 2048)), dim3(256), 0, s,
                      p.slabs, dw, nw, pl.nsplit);
-  if (dbias)
-    hipLaunchKernelGGL(slab_reduce_wave_kernel, dim3(cout), dim3(64), 0, s, bias_slabs, dbias, cout, n_bias_slabs);
+  if (dbias) {
+    constexpr int SEGS = 64;
+    if (n_bias_slabs > 8 * SEGS) {
+      // many rows: two stages (the partial rows live in the slab area of the workspace, free again by now --
+      // the weight slabs were consumed by the launch above; SEGS * cout floats always fit one weight slab)
+      const int rows_per_seg = st::cdiv(n_bias_slabs, SEGS);
+      hipLaunchKernelGGL(slab_reduce_rows_kernel, dim3(st::cdiv(cout, 16), SEGS), dim3(256), 0, s, bias_slabs, p.slabs,
+                         cout, n_bias_slabs, rows_per_seg);
+      hipLaunchKernelGGL(slab_reduce_wave_kernel, dim3(cout), dim3(64), 0, s, p.slabs, dbias, cout,
+                         st::cdiv(n_bias_slabs, rows_per_seg));
+    } else {
+      hipLaunchKernelGGL(slab_reduce_wave_kernel, dim3(cout), dim3(64), 0, s, bias_slabs, dbias, cout, n_bias_slabs);
+    }
+  }
   return st::check_launch("st_conv3x3_wgrad_bf16_pre(reduce)");
 }

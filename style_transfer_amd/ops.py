@@ -353,9 +353,9 @@ def conv3x3_dgrad_g8_chain(dy: torch.Tensor, w_packed_t: torch.Tensor, cin: int,
     g16 = torch.empty((n, cin, hs, ws), dtype=torch.bfloat16, device=dev) if want_g16 else None
     bias = None
     if want_bias:
-        slabs = lib.st_conv3x3_dgrad_fold8_bias_slabs(h, w, int(upsample2x))
+        slabs = lib.st_conv3x3_dgrad_chain_bias_slabs(n, cin, h, w, int(upsample2x))
         assert slabs > 0
-        bias = torch.empty((n * slabs, cin), dtype=torch.float32, device=dev)
+        bias = torch.empty((slabs, cin), dtype=torch.float32, device=dev)
     gate_g8 = dx_gate is not None and is_g8(dx_gate)
     if dx_gate is not None:
         assert tuple(dx_gate.shape) == ((n, cin // 8, hs, ws, 8) if gate_g8 else (n, cin, hs, ws)), "dx_gate shape"
