@@ -162,8 +162,7 @@ int st_conv3x3_dgrad_bf16_g8(const void* dy, int dy_g8, const void* w_packed_t, 
  * may be NULL): dx_f32 fp32 NCHW; dx_g8 G8 (operand of the next st_conv3x3_dgrad_bf16_g8_chain); dx_g16 bf16
  * [n][cin][h][w] and bias_slabs [st_conv3x3_dgrad_chain_bias_slabs(n, cin, h, w, up)][cin] fp32 partial sums
  * (operands of st_conv3x3_wgrad_bf16_pre of the layer below; every row is written).  Two forms, same fp32 values per
- * element: (1) with a G8 result and no fp32 one (every layer but the bottom of the chain), more than 32 channels and
- * an even (x4 under the upsample) h, w: the zero-padded conv on the UNPADDED grid with fold / gate / hand-over forms
+ * element: (1) with more than 32 channels, an even (x4 under the upsample) h, w and a source grid of at least 4 x 4: the zero-padded conv on the UNPADDED grid with fold / gate / hand-over forms
  * in its epilogue, then two small launches that redo the border source pixels from the padded-domain values of the
  * ring (csrc/dgrad_band.hip; `workspace` holds those); (2) otherwise the padded-domain result goes to `workspace`
  * and a second pass folds it.  `workspace`: st_conv3x3_dgrad_workspace_bytes(n, cin, h, w, ST_PAD_REPLICATE) for

@@ -82,6 +82,8 @@ struct ConvParams {
   const u32x4* egate_g8 = nullptr;   // G8, or
   const float* egate_f32 = nullptr;  // fp32 NCHW, or neither
   unsigned short* g16 = nullptr;     // optional: the same result as pixel-major bf16 [n][cout][hs][ws]
+  float* dxf = nullptr;              // optional: ... as fp32 NCHW [n][cout][hs][ws] (the bottom of the chain); y may be
+                                     // null then
   float* bslabs = nullptr;           // optional: [n * tiles per image * WP][cout] per-wave sums of the result over its
                                      // INTERIOR source pixels (the border ring is summed by the band kernels)
 };
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   if constexpr (EPI != 0) {
     constexpr bool UPF = (EPI & 3) == 2;
     constexpr bool GF32 = (EPI & 4) != 0;                   // the gate is fp32 NCHW (else G8, or none)
+    constexpr bool F32OUT = (EPI & 8) != 0;                 // the bottom of the chain: fp32 NCHW result (p.dxf)
     unsigned* patch = reinterpret_cast<unsigned*>(smem16 + (PERSIST ? 2 * C::W_UNITS + 2 * C::X_UNITS : 0) +
                                                   wave * 128);
     const u32x4* patch16 = reinterpret_cast<const u32x4*>(patch);
@@ -713,17 +716,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
             const int q = k * 2 + lh;
             const int cg = (cbase >> 3) + q;
             const u32x4 v4 = patch16[li * 4 + q];
-            if (cg < cgroups && sy < hs && sx < ws && !(p.ablate & 32))
+            if (yg && cg < cgroups && sy < hs && sx < ws && !(p.ablate & 32))
               yg[(size_t(b) * cgroups + cg) * plane_s + size_t(sy) * ws + sx] = v4;
           }
         } else {
           const int q = lane >> 4, px = lane & 15;
           const int cg = (cbase >> 3) + q;
           const u32x4 v4 = patch16[px * 4 + q];
-          if (cg < cgroups && sy < hs && (x0 >> 1) + px < ws)
+          if (yg && cg < cgroups && sy < hs && (x0 >> 1) + px < ws)
             yg[(size_t(b) * cgroups + cg) * plane_s + size_t(sy) * ws + (x0 >> 1) + px] = v4;
         }
         asm volatile("" ::: "memory");
+        if constexpr (F32OUT) {      // fp32 NCHW: an accumulator register is a row segment of one channel
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (ok && co < p.cout) p.dxf[(size_t(b) * p.cout + co) * plane_s + size_t(sy) * ws + sx] = v[r];
+          }
+        }
         // pixel-major bf16: lanes exchange one register of each pair so that a lane stores two neighbouring pixels
         // of ONE channel (4 B); 16 lanes cover a 64-B row segment (32 B under the upsample)
         if (p.g16) {
@@ -1307,17 +1317,20 @@ extern "C" int st_conv3x3_dgrad_bf16_g8_chain(const void* dy, int dy_g8, const v
   p.cout_pad = st::cdiv(cin, CPAD) * CPAD;
   p.nchunks = st::cdiv(cout, KC);
   p.pad_zero = 1; p.relu = 0; p.pool = 0;
-  if (chain_fused_ok(cin, h, w, up) && dx_g8 && !dx_f32) {
+  if (chain_fused_ok(cin, h, w, up) && !(dx_f32 && dx_gate && !dx_gate_g8)) {     // (fp32 result AND fp32 gate: form 2)
     // Fused form: the zero-padded conv on the unpadded grid with fold / gate / hand-over forms in its epilogue
     // (interior source pixels are final), then the band kernels recompute the border source pixels from the
     // padded-domain values of the ring and its neighbours and overwrite them.  No padded fp32 workspace round trip.
-    p.y = (float*)dx_g8; p.g16 = (unsigned short*)dx_g16; p.bslabs = bias_slabs;
+    p.y = (float*)dx_g8; p.g16 = (unsigned short*)dx_g16; p.bslabs = bias_slabs; p.dxf = dx_f32;
     p.egate_g8 = dx_gate_g8 ? (const u32x4*)dx_gate : nullptr;
     p.egate_f32 = dx_gate_g8 ? nullptr : (const float*)dx_gate;
     p.Ho = h; p.Wo = w; p.shift = 0; p.ldo = w;
     int rc;
     const bool xg = dy_g8 != 0;
-    if (p.egate_f32) {        // the top of the chain (64 <- 3 at full resolution): the one layer whose input is kept fp32
+    if (dx_f32 && !p.egate_f32) {       // the bottom of the chain hands fp32 back (with any bf16 form asked for as well)
+      if (cin > 64) rc = up ? launch_conv_chain<2, 4, 2, 4, 10>(p, xg, s) : launch_conv_chain<2, 4, 2, 4, 9>(p, xg, s);
+      else rc = up ? launch_conv_chain<2, 4, 1, 8, 10>(p, xg, s) : launch_conv_chain<2, 4, 1, 8, 9>(p, xg, s);
+    } else if (p.egate_f32) {  // the top of the chain (64 <- 3 at full resolution): the one layer whose input is kept fp32
       if (cin > 64) rc = up ? launch_conv_chain<2, 4, 2, 4, 6>(p, xg, s) : launch_conv_chain<2, 4, 2, 4, 5>(p, xg, s);
       else rc = up ? launch_conv_chain<2, 4, 1, 8, 6>(p, xg, s) : launch_conv_chain<2, 4, 1, 8, 5>(p, xg, s);
     } else {
@@ -1334,7 +1347,7 @@ extern "C" int st_conv3x3_dgrad_bf16_g8_chain(const void* dy, int dy_g8, const v
         if (e != hipSuccess) return st::fail(ST_ERR_LAUNCH, "st_conv3x3_dgrad_bf16_g8_chain: memset: %s", hipGetErrorString(e));
       }
     }
-    return st::launch_dgrad_band(dy, dy_g8, w_packed_t, workspace, p.egate_f32, p.egate_g8, nullptr, dx_g8, dx_g16,
+    return st::launch_dgrad_band(dy, dy_g8, w_packed_t, workspace, p.egate_f32, p.egate_g8, dx_f32, dx_g8, dx_g16,
                                  band_bias, n, cout, cin, h, w, up, s);
   }
   p.Ho = h + 2; p.Wo = w + 2; p.shift = 1;

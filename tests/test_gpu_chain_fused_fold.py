@@ -72,6 +72,27 @@ def test_fused_fold_equals_workspace_fold(n, k, c, h, w, up, dyf, gatef):
     torch.testing.assert_close(sb, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()) + 1e-3)
 
 
+@pytest.mark.parametrize("n,k,c,h,w,up", [(2, 256, 512, 8, 32, False), (1, 256, 512, 64, 64, False), (1, 64, 64, 16, 64, True)])
+def test_fused_fold_fp32_result_at_the_bottom_of_the_chain(n, k, c, h, w, up):
+    """The bottom layer hands fp32 NCHW back to AdaIN (no gate, no bf16 form): same bits from both forms."""
+    from style_transfer_amd import ops
+    g = torch.Generator().manual_seed(h * 1000 + w + k)
+    wt = torch.randn(k, c, 3, 3, generator=g) * (2.0 / (9 * k)) ** 0.5
+    wpt = ops.pack_conv3x3_weights(wt.cuda(), transpose_flip=True, compute="bf16")
+    dy = ops.to_g8((torch.randn(n, k, h, w, generator=g) * (torch.rand(n, k, h, w, generator=g) > 0.3)).cuda())
+    out = []
+    for fused in (False, True):
+        if not fused:
+            os.environ["ST_NO_FUSED_FOLD"] = "1"
+        try:
+            out.append(ops.conv3x3_dgrad_g8_chain(dy, wpt, c, up, None, want_f32=True, want_g8=False, want_g16=False,
+                                                  want_bias=False)[0])
+        finally:
+            os.environ.pop("ST_NO_FUSED_FOLD", None)
+    torch.cuda.synchronize()
+    assert float(out[0].abs().max()) > 0 and torch.equal(out[1], out[0])
+
+
 def test_bias_slab_count_covers_both_forms():
     from style_transfer_amd import _lib
     lib = _lib.load()

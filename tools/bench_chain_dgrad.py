@@ -16,7 +16,7 @@ n, S = args.batch, args.side
 LAYERS = [("L8 64<-3", 3, 64, S, False, "f32", "f32"), ("L7 64<-64 up", 64, 64, S, True, "g8", "g8"),
           ("L6 128<-64", 64, 128, S // 2, False, "g8", "g8"), ("L5 128<-128 up", 128, 128, S // 2, True, "g8", "g8"),
           ("L4 256<-128", 128, 256, S // 4, False, "g8", "g8"), ("L3 256<-256", 256, 256, S // 4, False, "g8", "g8"),
-          ("L1 256<-256 up", 256, 256, S // 4, True, "g8", "g8")]
+          ("L1 256<-256 up", 256, 256, S // 4, True, "g8", "g8"), ("L0 512<-256 f32out", 256, 512, S // 8, False, "g8", None)]
 g = torch.Generator(device="cuda").manual_seed(0)
 tot = {"fused": 0.0, "workspace": 0.0}
 for name, k, c, side, up, dyf, gf in LAYERS:
@@ -26,14 +26,16 @@ for name, k, c, side, up, dyf, gf in LAYERS:
     dy = ops.to_g8(dy) if dyf == "g8" else dy
     s = 2 if up else 1
     act = torch.relu(torch.randn(n, c, side // s, side // s, device="cuda", generator=g))
-    gate = ops.to_g8(act) if gf == "g8" else act
+    gate = ops.to_g8(act) if gf == "g8" else (act if gf == "f32" else None)
+    bottom = gf is None
     row = []
     for mode in ("fused", "workspace"):
         if mode == "workspace":
             os.environ["ST_NO_FUSED_FOLD"] = "1"
         else:
             os.environ.pop("ST_NO_FUSED_FOLD", None)
-        f = lambda: ops.conv3x3_dgrad_g8_chain(dy, wpt, c, up, gate, False, True, True, True)
+        f = (lambda: ops.conv3x3_dgrad_g8_chain(dy, wpt, c, up, None, True, False, False, False)) if bottom else \
+            (lambda: ops.conv3x3_dgrad_g8_chain(dy, wpt, c, up, gate, False, True, True, True))
         for _ in range(3):
             f()
         torch.cuda.synchronize()
