@@ -122,6 +122,69 @@ def conv3x3_padded(xp: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.
 
 
 # --------------------------------------------------------------------------
+# gates: the piecewise-linear switches of the training step (ReLU masks, max-pool winners, the [0, 1] clamp of
+# losses.py:170).  Two fp32 implementations of the step agree on all but a few isolated switches (a 1e-7 forward
+# difference flips one now and then) and everything below a flipped switch moves, so whole-step GRADIENTS are
+# compared with the switches pinned: ``with gates("record") as g:`` stores the switches this oracle takes under
+# their names, ``with gates("force", g):`` makes it take the stored ones (from its own run, or from the other
+# implementation's activations) instead of deciding itself.  Forced forward values are the linear branch's
+# (``x * mask``, the chosen window element, ``x`` inside the clamp / the constant outside); gradients follow the
+# mask exactly.  Names: "dec.{idx}" (decoder ReLUs, generator.py:89-116), "{tag}.relu.{idx}" / "{tag}.pool.{idx}"
+# (loss VGG, trainer.py:165-199), "hist" (losses.py:170).  Test infrastructure; the reference has no such thing.
+# --------------------------------------------------------------------------
+
+GATES = None        # None | ("record", dict) | ("force", dict)
+
+
+class gates:
+    def __init__(self, mode: str, store: dict = None):
+        assert mode in ("record", "force")
+        self.mode, self.store = mode, ({} if store is None else store)
+
+    def __enter__(self):
+        global GATES
+        self.prev, GATES = GATES, (self.mode, self.store)
+        return self.store
+
+    def __exit__(self, *exc):
+        global GATES
+        GATES = self.prev
+
+
+def _relu(x: torch.Tensor, name=None) -> torch.Tensor:
+    if GATES is None or name is None:
+        return F.relu(x)
+    mode, store = GATES
+    if mode == "record":
+        store[name] = (x > 0).detach()
+        return F.relu(x)
+    return x * store[name].to(x.dtype)
+
+
+def _max_pool(x: torch.Tensor, name=None, ceil_mode: bool = False) -> torch.Tensor:
+    if GATES is None or name is None:
+        return F.max_pool2d(x, 2, 2, 0, ceil_mode=ceil_mode)
+    mode, store = GATES
+    if mode == "record":
+        y, idx = F.max_pool2d(x, 2, 2, 0, ceil_mode=ceil_mode, return_indices=True)
+        store[name] = idx.detach()
+        return y
+    idx = store[name]
+    return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+
+
+def _clamp01(x: torch.Tensor, name=None) -> torch.Tensor:
+    if GATES is None or name is None:
+        return torch.clamp(x, 0, 1)
+    mode, store = GATES
+    if mode == "record":
+        store[name] = ((x >= 0) & (x <= 1)).detach(), (x > 1).detach()      # torch.clamp passes the gradient on [0, 1]
+        return torch.clamp(x, 0, 1)
+    inside, above = store[name]
+    return torch.where(inside, x, above.to(x.dtype))
+
+
+# --------------------------------------------------------------------------
 # generator.py
 # --------------------------------------------------------------------------
 
@@ -161,13 +224,14 @@ def encoder_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tenso
     return x
 
 
-def decoder_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = "decoder.") -> torch.Tensor:
-    """Decoder.forward (generator.py:85-130).  Keys ``decoder.{1,...,28}.{weight,bias}``."""
+def decoder_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = "decoder.",
+                    gate_tag: str = None) -> torch.Tensor:
+    """Decoder.forward (generator.py:85-130).  Keys ``decoder.{1,...,28}.{weight,bias}``.  ``gate_tag``: see gates."""
     for idx, _cin, _cout in DECODER_CONVS:
         w, b = sd[f"{prefix}{idx}.weight"], sd[f"{prefix}{idx}.bias"]
         x = conv3x3_padded(symmetric_pad(x), w, b)
         if idx != 28:
-            x = F.relu(x)
+            x = _relu(x, f"{gate_tag}.{idx}" if gate_tag else None)
         if idx in DECODER_UP_AFTER:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
     return x
@@ -271,7 +335,8 @@ def make_loss_vgg_state(seed: int = 2, upto: int = 36, dtype=torch.float32) -> D
     return sd
 
 
-def loss_vgg_features(x: torch.Tensor, sd: Dict[str, torch.Tensor], indices: Sequence[int]) -> List[torch.Tensor]:
+def loss_vgg_features(x: torch.Tensor, sd: Dict[str, torch.Tensor], indices: Sequence[int],
+                      gate_tag: str = None) -> List[torch.Tensor]:
     """Trainer.get_feature_extractor + IntermediateLayerGetter (trainer.py:165-199,
     446-454).  PARITY UNPINNED (torchvision not importable here).
 
@@ -290,11 +355,11 @@ def loss_vgg_features(x: torch.Tensor, sd: Dict[str, torch.Tensor], indices: Seq
         if kind == "conv":
             x = conv3x3_padded(F.pad(x, (1, 1, 1, 1)), sd[f"{idx}.weight"], sd[f"{idx}.bias"])
         elif kind == "relu":
-            x = F.relu(x)
+            x = _relu(x, f"{gate_tag}.relu.{idx}" if gate_tag else None)
             if idx - 1 in outs:          # in-place aliasing of the captured conv output
                 outs[idx - 1] = x
         else:
-            x = F.max_pool2d(x, 2, 2)
+            x = _max_pool(x, f"{gate_tag}.pool.{idx}" if gate_tag else None)
         if idx in wanted:
             outs[idx] = x
     # dict order of IntermediateLayerGetter = layer order; trainer indexes the
@@ -383,13 +448,14 @@ class hist_kernel_dtype:
 
 def rgbuv_hist(x: torch.Tensor, h: int = 64, insz: int = 128, method: str = "inverse-quadratic",
                sigma: float = 0.02, intensity_scale: bool = True,
-               hist_boundary=(-3.0, 3.0), resizing: str = "interpolation", green_only: bool = False) -> torch.Tensor:
+               hist_boundary=(-3.0, 3.0), resizing: str = "interpolation", green_only: bool = False,
+               gate_name: str = None) -> torch.Tensor:
     """RGBuvHistBlock.forward (losses.py:169-322).  Bin centres are float64 (np.linspace, losses.py:211-213),
     so the kernel weights are evaluated in float64 and cast to float32
     (losses.py:239-240) before the [h,N]x[N,h] product.  'sampling' picks h (sic: the bin count, losses.py:176-181)
     rows and columns; green_only keeps the G pairing alone (losses.py:195-196, 278-281)."""
     lo, hi = sorted(hist_boundary)
-    x = torch.clamp(x, 0, 1)
+    x = _clamp01(x, gate_name)
     if x.shape[2] > insz or x.shape[3] > insz:
         if resizing == "interpolation":
             x = F.interpolate(x, size=(insz, insz), mode="bilinear", align_corners=False)
@@ -437,9 +503,9 @@ def rgbuv_hist(x: torch.Tensor, h: int = 64, insz: int = 128, method: str = "inv
     return hists / (hists.sum(dim=(1, 2, 3)).view(-1, 1, 1, 1) + HIST_EPS)
 
 
-def hist_loss(inp: torch.Tensor, tgt: torch.Tensor, **kw) -> torch.Tensor:
+def hist_loss(inp: torch.Tensor, tgt: torch.Tensor, gate_name: str = None, **kw) -> torch.Tensor:
     """HistLoss.forward (losses.py:338-347): Hellinger, sqrt OUTSIDE the batch sum."""
-    ih = rgbuv_hist(inp, **kw)
+    ih = rgbuv_hist(inp, gate_name=gate_name, **kw)
     th = rgbuv_hist(tgt, **kw)
     return (1 / np.sqrt(2.0) * torch.sqrt(torch.sum((torch.sqrt(th) - torch.sqrt(ih)) ** 2)) / ih.shape[0]) * 100
 
@@ -451,7 +517,7 @@ def compute_loss(content_feats, style_feats, stylized, style_imgs, content_imgs,
     loss_content = sum(content_loss(o, t) for o, t in content_feats)
     loss_style = sum(style_fn(o, t) for o, t in style_feats)
     variation = tv_loss(stylized)
-    hist = 0.4 * hist_loss(stylized, style_imgs) + 0.6 * hist_loss(stylized, content_imgs)
+    hist = 0.4 * hist_loss(stylized, style_imgs, gate_name="hist") + 0.6 * hist_loss(stylized, content_imgs, gate_name="hist")
     total = alpha * loss_content + beta * loss_style + gamma * variation + delta * hist
     return loss_content, loss_style, variation, hist, total
 
@@ -474,16 +540,25 @@ def stylize(content: torch.Tensor, style: torch.Tensor, enc_sd, dec_sd,
 
 def train_step_losses(content, style, enc_sd, dec_sd, vgg_sd, content_eps_param, style_eps_param,
                       eps_limit, content_layers_idx, style_layers_idx,
-                      alpha, beta, gamma, delta, use_vincent=False):
-    """Forward half of the train-step body (trainer.py:426-464)."""
+                      alpha, beta, gamma, delta, use_vincent=False, decoded_override=None):
+    """Forward half of the train-step body (trainer.py:426-464).
+
+    ``decoded_override`` (tests only): the decoded image of ANOTHER implementation of the same step.  Everything
+    after the decoder is evaluated at those values while gradients still flow into this decoder
+    (``dec + (override - dec).detach()``): the loss terms whose gradient is very sensitive to the last bits of the
+    decoded image (the histogram's 1 / (x + 1e-6)) can then be compared at identical input."""
     fc = encoder_forward(content, enc_sd)
     fs = encoder_forward(style, enc_sd)
     t = adain_forward(fc, fs, content_eps_param, style_eps_param, eps_limit)
     t = 1.0 * t + (1 - 1.0) * fc
-    dec = decoder_forward(t, dec_sd)
+    dec = decoder_forward(t, dec_sd, gate_tag="dec")
+    if decoded_override is not None:
+        dec = dec + (decoded_override.to(dec.dtype) - dec).detach()
     c_n, s_n, d_n = normalize(content), normalize(style), normalize(dec)
-    cf = list(zip(loss_vgg_features(d_n, vgg_sd, content_layers_idx),
+    # (gates: only the passes a gradient flows through carry names -- the decoder and the decoded image's two
+    # extractor passes, which see the same input and therefore the same switches)
+    cf = list(zip(loss_vgg_features(d_n, vgg_sd, content_layers_idx, gate_tag="vgg"),
                   loss_vgg_features(c_n, vgg_sd, content_layers_idx)))
-    sf = list(zip(loss_vgg_features(d_n, vgg_sd, style_layers_idx),
+    sf = list(zip(loss_vgg_features(d_n, vgg_sd, style_layers_idx, gate_tag="vgg"),
                   loss_vgg_features(s_n, vgg_sd, style_layers_idx)))
     return compute_loss(cf, sf, d_n, s_n, c_n, alpha, beta, gamma, delta, use_vincent)

@@ -16,10 +16,12 @@ class Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cache, key, upsample2x, pad_mode, relu):
         cout = int(weight.shape[0])
-        wp = cache.get(key, weight, False)
+        # (fp32 mode, replicate-padded layer behind the x2 upsample: sub-pixel forward, see DecoderChainFunction)
+        wp = cache.get(key, weight, False, upsample2x=bool(upsample2x) and ops._pad_code(pad_mode) == ops.PAD_REPLICATE)
         y = ops.conv3x3(x, wp, bias.detach() if bias is not None else None, cout, upsample2x, pad_mode, relu)
         ctx.cache, ctx.key = cache, key
-        ctx.compute = ops.conv_family(wp, int(weight.shape[0]), int(weight.shape[1]))   # backward uses the forward's precision
+        fam = ops.conv_family(wp, int(weight.shape[0]), int(weight.shape[1]))           # backward uses the forward's precision
+        ctx.compute = "f32" if fam == "f32up2" else fam
         ctx.upsample2x, ctx.pad_mode, ctx.relu = upsample2x, pad_mode, relu
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -72,19 +74,29 @@ class DecoderChainFunction(torch.autograd.Function):
     kernels.  The write OVERWRITES: valid because the trainer runs the decoder once per backward.
     """
 
+    #: test hook: a list to receive the layer outputs of the next forward (tests/test_gpu_parity_step.py reads the
+    #: ReLU masks the step actually took); None in every other use
+    TAP = None
+
     @staticmethod
     def forward(ctx, x, cache, specs, *params):
         acts = [x]
         compute = []        # per layer: the backward of a layer uses its forward's precision
         for i, (key, cout, up, relu) in enumerate(specs):
             w, b = params[2 * i], params[2 * i + 1]
-            # (the sub-pixel form of the upsample layers is kept to forward-only calls: the training step's float64
-            # arbiter test, tests/test_gpu_parity_step.py, is calibrated on the direct form's rounding pattern)
-            wp = cache.get(key, w, False)
-            compute.append(ops.conv_family(wp, int(w.shape[0]), int(w.shape[1])))
+            # fp32 mode: a layer behind the x2 upsample runs its FORWARD in the sub-pixel form (16 instead of 36
+            # multiply-adds per source pixel and channel pair, the same products regrouped; generator.py:92-93,
+            # 105-106, 112-113) under autograd as well; its data and weight gradients are the direct form's (the
+            # adjoint of the same linear map).  Whole-step gradient parity no longer depends on which last-bit
+            # rounding the forward has: tests/test_gpu_parity_step.py pins the switches instead.
+            wp = cache.get(key, w, False, upsample2x=up)
+            fam = ops.conv_family(wp, int(w.shape[0]), int(w.shape[1]))
+            compute.append("f32" if fam == "f32up2" else fam)
             acts.append(ops.conv3x3(acts[-1], wp, b.detach(), cout, up, ops.PAD_REPLICATE, relu))
         ctx.cache, ctx.specs, ctx.compute = cache, specs, compute
         ctx.save_for_backward(*acts[:-1], *params)          # layer inputs (the last output is not needed)
+        if DecoderChainFunction.TAP is not None:
+            DecoderChainFunction.TAP.extend(a.detach() for a in acts[1:])
         return acts[-1]
 
     @staticmethod

@@ -223,3 +223,40 @@ def test_custom_transforms_against_reference_vectors():
         else:
             assert torch.equal(out, x)
     assert applied >= 5
+
+
+def test_oracle_gates_record_then_force_is_the_same_step():
+    """oracle.ref_ops.gates: forcing the switches the oracle recorded from its own run reproduces its losses and
+    gradients (forced forward values are x * mask / the recorded window element / x inside the clamp: the same
+    numbers), and forcing a DIFFERENT ReLU mask changes the gradient below it -- the hook really steers the branch."""
+    enc_sd, dec_sd0, vgg_sd = R.make_encoder_state(0), R.make_decoder_state(1), R.make_loss_vgg_state(2, upto=25)
+    g = torch.Generator().manual_seed(3)
+    c, s = torch.rand(1, 3, 32, 32, generator=g), torch.rand(1, 3, 32, 32, generator=g)
+
+    def run(mode=None, store=None):
+        dec = {k: v.clone().requires_grad_(True) for k, v in dec_sd0.items()}
+        ce, se = torch.tensor([1e-5], requires_grad=True), torch.tensor([1e-5], requires_grad=True)
+        args = (c, s, enc_sd, dec, vgg_sd, ce, se, 0.1, [21], [2, 7, 14, 19, 25], 1.0, 10.0, 1.0, 10.0, False)
+        if mode is None:
+            out = R.train_step_losses(*args)
+        else:
+            with R.gates(mode, store):
+                out = R.train_step_losses(*args)
+        out[4].backward()
+        return [float(v) for v in out], dec["decoder.21.weight"].grad.clone(), dec["decoder.1.weight"].grad.clone()
+    plain = run()
+    store = {}
+    rec = run("record", store)
+    forced = run("force", store)
+    assert {"dec.1", "dec.25", "vgg.relu.1", "vgg.pool.4", "vgg.relu.24", "hist"} <= set(store)
+    assert "dec.28" not in store and "vgg.relu.26" not in store
+    for a, b in ((plain, rec), (plain, forced)):
+        assert a[0] == pytest.approx(b[0], rel=1e-6)
+        torch.testing.assert_close(a[1], b[1], rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-9)
+    flipped = dict(store)
+    m = store["dec.25"].clone()
+    m[0, :, :4, :4] = ~m[0, :, :4, :4]
+    flipped["dec.25"] = m
+    other = run("force", flipped)
+    assert float((other[1] - plain[1]).norm() / plain[1].norm()) > 1e-4
