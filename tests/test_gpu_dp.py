@@ -63,7 +63,7 @@ def _trajectory(run, bucket, decoder, transformer, batches, lo, hi):
 RUNS = (("frozen", False, TINY_LR), ("eager", False, 1e-4), ("graph", True, 1e-4))
 
 
-def _worker(rank, world, port, q, compute="f32", runs=RUNS):
+def _worker(rank, world, port, q, compute="f32", runs=RUNS, per_rank=PER_RANK):
     sys.path.insert(0, REPO)
     from style_transfer_amd import precision
     from style_transfer_amd.parallel import init_process_group
@@ -71,14 +71,14 @@ def _worker(rank, world, port, q, compute="f32", runs=RUNS):
     dist, _ = init_process_group(rehearsal=True, local_rank=rank, init_method=f"tcp://127.0.0.1:{port}",
                                  rank=rank, world_size=world)
     batches = _batches()
-    lo = rank * PER_RANK
+    lo = rank * per_rank
     result = {}
     # "frozen": lr = 0, the weights stay put, so EVERY step compares gradients of identical
     # weights on a new batch; the other two runs take real Adam steps (lr 1e-4), eager and graph-replayed
     for name, use_graph, lr_value in runs:
         tr, run, bucket, decoder, transformer = _make(use_graph=use_graph, lr_value=lr_value)
         assert tr.world_size == world and tr.graph_capable()
-        grads, losses, weights = _trajectory(run, bucket, decoder, transformer, batches, lo, lo + PER_RANK)
+        grads, losses, weights = _trajectory(run, bucket, decoder, transformer, batches, lo, lo + per_rank)
         if use_graph:
             assert len(run.graphs) == 3 and run.replays == STEPS - run.WARMUP
         # every rank's losses (content / style / variation are per-rank means, hist is already batch-wide)
@@ -98,10 +98,10 @@ def _rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _two_ranks(port, compute="f32", runs=RUNS):
+def _two_ranks(port, compute="f32", runs=RUNS, world=WORLD, per_rank=PER_RANK):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q, compute, runs)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, compute, runs, per_rank)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -148,6 +148,33 @@ def test_two_rank_step_equals_large_batch_step():
             assert torch.allclose(a, b, rtol=1e-5, atol=0), (step, r, a, b)
         assert _rel_l2(gr["grads"][step], got["grads"][step]) < 1e-5, step
     assert _rel_l2(gr["weights"], got["weights"]) < 1e-5
+
+
+def test_four_rank_step_equals_large_batch_step():
+    """4 ranks x 1 image (the same four-image batches): the reduced gradient bucket, the clamped eps gradients and the
+    losses equal the single-process 4-image step, eagerly and replayed from the three HIP graphs around the two
+    collectives -- more ranks than the 2-rank test, the smallest per-rank batch."""
+    world, per_rank = 4, 1
+    both = _two_ranks(29800 + os.getpid() % 2000, "f32", (("frozen", False, TINY_LR), ("eager", False, 1e-4), ("graph", True, 1e-4)),
+                      world=world, per_rank=per_rank)
+    got = both["frozen"]
+    tr, run, bucket, decoder, transformer = _make(world_size_override=1, use_graph=False, lr_value=TINY_LR)
+    grads, losses, weights = _trajectory(run, bucket, decoder, transformer, _batches(), 0, per_rank * world)
+    for step in range(STEPS):
+        ref_l = losses[step].double()
+        dp = torch.stack([torch.as_tensor(l[step]).double() for l in got["losses"]])
+        assert dp.shape[0] == world
+        for i, name in enumerate(("content", "style", "variation")):
+            assert float(dp[:, i].mean()) == pytest.approx(float(ref_l[i]), rel=2e-5), (step, name)
+        for r in range(world):
+            assert float(dp[r, 3]) == pytest.approx(float(ref_l[3]), rel=2e-5), (step, "hist", r)
+        assert _rel_l2(got["grads"][step], grads[step]) < 2e-4, step
+        assert float(torch.as_tensor(got["grads"][step][:2]).abs().max()) <= 2e-3 + 1e-9
+    assert _rel_l2(got["weights"], weights) < 1e-6
+    gr, eg = both["graph"], both["eager"]
+    for step in range(STEPS):
+        assert _rel_l2(gr["grads"][step], eg["grads"][step]) < 1e-5, step
+    assert _rel_l2(gr["weights"], eg["weights"]) < 1e-5
 
 
 def test_two_rank_step_equals_large_batch_step_in_bf16_compute_mode():

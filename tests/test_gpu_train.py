@@ -120,6 +120,47 @@ def test_trainer_loop_and_checkpoint(tmp_path):
     assert [h["epoch"] for h in hist2] == [2]
 
 
+def test_log_steps_rows_are_the_per_step_losses(tmp_path, capsys):
+    """``--log_steps`` (Trainer(log_steps=True)): the five per-batch scalars of trainer.py:475-480, kept on the device
+    during the epoch and read once at its end -- every row equals what the same step returns when it is driven
+    eagerly one batch at a time (same weights trajectory: same seeds, same optimizer), and the rows are printed."""
+    from style_transfer_amd.trainer import GradBucket, Trainer
+
+    class Loader(list):
+        dataset = list(range(6))
+
+    g = torch.Generator().manual_seed(9)
+    batches = Loader([{"content_image": torch.rand(2, 3, 32, 32, generator=g),
+                       "style_image": torch.rand(2, 3, 32, 32, generator=g)} for _ in range(3)])
+    kw = dict(output_dir=str(tmp_path), num_train_epochs=1, per_device_batch_size=2, learning_rate=1e-3,
+              alpha=1.0, beta=10.0, gamma=1.0, delta=10.0, eps=0.1, save_best=False, do_decoder_train=True,
+              optim_name={"optim_name": "adam"}, content_layers_idx=[21], style_layers_idx=[2, 7, 14, 19, 25],
+              encoder_weights=R.make_encoder_state(0), vgg_weights=R.make_loss_vgg_state(2, upto=25),
+              decoder_weights={k.removeprefix("decoder."): v for k, v in R.make_decoder_state(1).items()},
+              use_pretrained_WCTDECODER=True, step_frequency=10.0)       # (no LR step inside the epoch)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hist = Trainer({"train": batches}, log_steps=True, **kw).train()
+        rows = hist[0]["steps"]
+        assert len(rows) == 3 and all(len(r) == 5 for r in rows)
+        printed = capsys.readouterr().out
+        assert "step 0: content" in printed and "step 2: content" in printed
+        # the same three steps, driven by hand
+        tr = Trainer({"train": batches}, **dict(kw, output_dir=str(tmp_path / "by_hand")))
+        encoder, decoder, transformer, loss_vgg = tr.build_model()
+        params = tr.trainable_parameters(transformer, decoder)
+        opt = tr.get_optimizer("adam", params, 1e-3, {"optim_name": "adam"})
+        step, bucket = tr.make_step(encoder, decoder, transformer, loss_vgg), GradBucket(params)
+        for row, b in zip(rows, batches):
+            out = tr.optimize_step(step, opt, bucket, b["content_image"].cuda(), b["style_image"].cuda())
+            for got, want in zip(row, out):
+                assert got == pytest.approx(float(want), rel=1e-5), (row, [float(v) for v in out])
+    # the epoch means the trainer reports are the means of those rows
+    for i, k in enumerate(("content", "style", "variation", "hist", "total")):
+        assert hist[0][k] == pytest.approx(sum(r[i] for r in rows) / 3, rel=1e-5)
+
+
 def _trainer_for_steps(use_graph):
     import warnings
     from style_transfer_amd.trainer import GradBucket, GraphedStep, Trainer

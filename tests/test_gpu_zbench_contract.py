@@ -91,3 +91,30 @@ def test_bench_under_launcher_on_real_rccl_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "dp1" in d["config"]["parallelism"]
     assert d["hip_graph"]["value"] > 0 and "three HIP graph" in d["hip_graph"]["launch"], d["hip_graph"]
+
+
+def test_bench_gpus_2_train_mode_rehearsal_has_no_failed_leg():
+    """`python bench.py --gpus 2 --mode train --no-bf16 --no-gram` (what a data-parallel scaling run executes per N, at
+    rehearsal sizes): finishes, reports n_gpus 2 from rank 0 alone, and NO leg carries an "error" key (the secondary
+    legs are guarded under a launcher: a failure would be recorded instead of raised)."""
+    env = dict(os.environ, ST_BENCH_REHEARSAL="1", ST_BENCH_PREWARM="0.05")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--mode", "train", "--no-bf16", "--no-gram",
+         "--train-batch", "2", "--train-side", "64", "--train-steps", "3", "--train-warmup", "1"],
+        capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["metric"] == "train img/s" and d["value"] > 0 and d["scaling"] == "weak"
+    assert "dp2" in d["config"]["parallelism"]
+
+    def errors(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k == "error":
+                    yield path
+                yield from errors(v, f"{path}/{k}")
+    assert list(errors(d)) == [], list(errors(d))
+    assert d["hip_graph"]["value"] > 0 and "three HIP graph" in d["hip_graph"]["launch"]

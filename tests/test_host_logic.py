@@ -100,8 +100,10 @@ def _dp_worker(rank, world, port, q):
     w = torch.nn.Parameter(torch.tensor([0.8, 1.1, 0.9]).view(1, 3, 1, 1))
     b = torch.nn.Parameter(torch.tensor([0.05, -0.02, 0.01]).view(1, 3, 1, 1))
     g = torch.Generator().manual_seed(11)
-    x_all = torch.rand(4, 3, 12, 12, generator=g)
-    t_all = torch.rand(4, 3, 12, 12, generator=g)
+    per = 2 if world == 2 else 1                  # world 2: 2 images per rank; world 8: one image per rank
+    total = per * world
+    x_all = torch.rand(total, 3, 12, 12, generator=g)
+    t_all = torch.rand(total, 3, 12, 12, generator=g)
 
     def loss_fn(x, t, reduce_q, global_batch):
         img = w * x + b
@@ -111,13 +113,14 @@ def _dp_worker(rank, world, port, q):
         hist = (1 / (2.0 ** 0.5) * torch.sqrt(qv) / global_batch) * 100
         return R.tv_loss(img) + 10.0 * hist
 
-    lo, hi = rank * 2, rank * 2 + 2
-    loss = loss_fn(x_all[lo:hi], t_all[lo:hi], allreduce_q, 4)
+    torch.set_num_threads(1)                      # eight ranks share this container's eight cores
+    lo, hi = rank * per, rank * per + per
+    loss = loss_fn(x_all[lo:hi], t_all[lo:hi], allreduce_q, total)
     loss.backward()
     GradBucket([w, b]).reduce_mean()
     dp = torch.cat([w.grad.flatten(), b.grad.flatten()]).clone()
     w.grad = None; b.grad = None
-    full = loss_fn(x_all, t_all, lambda v: v, 4)
+    full = loss_fn(x_all, t_all, lambda v: v, total)
     full.backward()
     ref = torch.cat([w.grad.flatten(), b.grad.flatten()])
     if rank == 0:
@@ -126,13 +129,14 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_data_parallel_gradients_equal_large_batch():
-    """Batch sharded over 2 ranks + bucket mean all-reduce + all-reduced Hellinger scalar ==
-    single-process gradients on the whole batch."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_data_parallel_gradients_equal_large_batch(world):
+    """Batch sharded over 2 ranks (8 ranks: BASELINE configs[3]'s world size, one image per rank) + bucket mean
+    all-reduce + all-reduced Hellinger scalar == single-process gradients on the whole batch."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 2000 + 7 * world
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     dp, ref = q.get(timeout=240)
