@@ -194,6 +194,15 @@ int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g16, const fl
  * st_relu_bwd followed by the bf16 rounding of the data-gradient kernel's staging. */
 int st_grad_join_g8(const float* chain, const float* chain_pooled, const float* x_gate, const float* add_post,
                     const float* add_pre, void* out_g8, int n, int c, int h, int w, st_stream_t stream);
+/* The same with a loss gradient handed over as per-plane AFFINE COEFFICIENTS instead of a tensor: the gradient of
+ * AdaINStyleLoss (losses.py:14-39) w.r.t. a tap t is k0 + k1 * (t - mean) per (image, channel) plane, so the join
+ * evaluates it from the tap it reads anyway and the [n][c][h][w] fp32 gradient is never written or re-read.
+ * aff_post / aff_pre: [n * c][4] = (k0, k1, mean, -) from st_meanstd_loss_bwd_coeffs, in place of add_post / add_pre
+ * (either may be NULL; not together with the tensor form of the same term); aff_x: the tap tensor (== x_gate when
+ * that is given with chain_pooled).  Same fp32 expression as st_meanstd_loss_bwd: identical values. */
+int st_grad_join_g8_affine(const float* chain, const float* chain_pooled, const float* x_gate, const float* add_post,
+                           const float* add_pre, const float* aff_x, const float* aff_post, const float* aff_pre,
+                           void* out_g8, int n, int c, int h, int w, st_stream_t stream);
 /* The same for the bf16x3 mode (weights from st_conv3x3_pack_weights_bf16x3): a "G8" activation is the hi/lo pair
  * form bf16 [n][c/8][2][h][w][8] with part 0 = bf16(v) and part 1 = bf16(v - part 0) -- the split the kernels apply
  * to an fp32 activation, done once by the producing layer; as many bytes as fp32, staged by LDS-DMA.  Bit-identical
@@ -332,6 +341,10 @@ int st_meanstd_loss_fwd(const float* mean_a, const float* std_a, const float* me
 int st_meanstd_loss_bwd(const float* x, const float* mean_a, const float* std_a, const float* mean_b,
                         const float* std_b, const float* gout, float scale, float* dx, int planes,
                         int hw, int accumulate, st_stream_t stream);
+/* The per-plane scalars of that backward, coeffs [planes][4] = (k0, k1, mean_a, 0) with dx = k0 + k1 * (x - mean_a):
+ * for st_grad_join_g8_affine. */
+int st_meanstd_loss_bwd_coeffs(const float* mean_a, const float* std_a, const float* mean_b, const float* std_b,
+                               const float* gout, float scale, float* coeffs, int planes, int hw, st_stream_t stream);
 
 /* ---- RGB-uv histogram (RGBuvHistBlock.forward, losses.py:169-322; 'interpolation' resizing,
  * all three pairings, h <= 64) and the Hellinger distance of HistLoss (losses.py:338-347) -------

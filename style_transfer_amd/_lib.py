@@ -45,6 +45,10 @@ SIGNATURES = {
                                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "st_grad_join_g8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p]),
+    "st_grad_join_g8_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_meanstd_loss_bwd_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                                           c_int, c_void_p]),
     "st_conv3x3_dgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_void_p]),

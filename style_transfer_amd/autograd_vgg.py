@@ -25,6 +25,35 @@ import torch
 from . import ops
 
 
+# ---- loss gradients handed over as per-plane affine coefficients -------------------------------------------------------
+# A loss whose gradient w.r.t. a tap is affine in the tap per (image, channel) plane (AdaINStyleLoss) returns, from its
+# autograd backward, a PLACEHOLDER of the tap's shape -- one NaN element expanded with stride 0, nothing materialised --
+# and leaves the coefficients here under the placeholder's address; VGGChainFunction.backward recognises the
+# placeholder and passes the coefficients to the join kernel.  Only taps with exactly ONE consumer are marked for this
+# (``_st_chain_tap``, set in loss_network._forward_multi_chain); should autograd ever add the placeholder to another
+# gradient, the NaN makes that visible at once instead of silently dropping a term.
+_AFFINE: Dict[int, torch.Tensor] = {}
+AFFINE_TAPS = True          # ST_NO_AFFINE_TAPS=1 (read in loss_network) keeps the tensor hand-over
+
+
+def lazy_affine_grad(tap: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
+    holder = torch.full((1,), float("nan"), dtype=tap.dtype, device=tap.device)
+    if len(_AFFINE) > 256:      # placeholders no chain backward collected (a tap used outside the chain): drop them
+        _AFFINE.clear()
+    # the registry keeps ``holder`` alive, so no other tensor can sit at its address while the entry exists
+    _AFFINE[holder.data_ptr()] = (holder, coeffs)
+    return holder.expand(tap.shape)
+
+
+def take_affine(g):
+    """(coefficients, None) if ``g`` is a lazy_affine_grad placeholder, else (None, contiguous g)."""
+    if g is None:
+        return None, None
+    if g.dim() == 4 and g.stride() == (0, 0, 0, 0) and g.data_ptr() in _AFFINE:
+        return _AFFINE.pop(g.data_ptr())[1], None
+    return None, g.contiguous()
+
+
 def plan_units(layout, last_all: int) -> List[Tuple]:
     """[("conv", idx, has_relu) | ("pool", idx)] for layers 0..last_all (a conv's in-place ReLU is part of its unit)."""
     units, idx = [], 0
@@ -116,6 +145,7 @@ class VGGChainFunction(torch.autograd.Function):
             meta.append(m)
         keys = VGGChainFunction.keys(net.layout, last_all, pre, post)
         ctx.net, ctx.meta, ctx.out_keys, ctx.x_shape = net, meta, keys, tuple(x.shape)
+        ctx.pre_idx = frozenset(pre)
         ctx.save_for_backward(*saved)
         return tuple(outs[k] for k in keys)
 
@@ -123,7 +153,9 @@ class VGGChainFunction(torch.autograd.Function):
     def backward(ctx, *gouts):
         net, meta = ctx.net, ctx.meta
         saved = ctx.saved_tensors
-        grads = {k: (g.contiguous() if g is not None else None) for k, g in zip(ctx.out_keys, gouts)}
+        grads, affs = {}, {}
+        for key, gout in zip(ctx.out_keys, gouts):
+            affs[key], grads[key] = take_affine(gout)
         kind, g = None, None            # gradient w.r.t. the OUTPUT of the unit being visited: "f32" | "g8" | "pooled"
         dx = None
         for k in range(len(meta) - 1, -1, -1):
@@ -131,6 +163,7 @@ class VGGChainFunction(torch.autograd.Function):
             if m["kind"] == "pool":
                 assert kind in (None, "f32")
                 tap = grads.get(("post", m["idx"]))
+                assert affs.get(("post", m["idx"])) is None, "pool outputs are never marked for the affine hand-over"
                 if g is not None and tap is not None:
                     g = g + tap
                 elif tap is not None:
@@ -146,13 +179,25 @@ class VGGChainFunction(torch.autograd.Function):
                 chain = g if kind == "f32" else None
                 pooled = g if kind == "pooled" else None
                 add_post, add_pre = grads.get(("post", idx)), grads.get(("pre", idx))
+                aff_post, aff_pre = affs.get(("post", idx)), affs.get(("pre", idx))
                 gate = y if m["relu"] else None
                 if pooled is not None and (m["shape"][2] % 2 or m["shape"][3] % 2):
                     chain, pooled = ops.maxpool2x2_bwd(y, pooled, False), None      # odd sizes: separate pool backward
-                if chain is None and pooled is None and add_post is None and add_pre is None:
+                if aff_post is not None and aff_pre is not None:
+                    raise RuntimeError("VGGChainFunction: affine loss gradients on both captures of one layer")
+                if aff_pre is not None and m["relu"]:
+                    # the saved tensor of a pre-captured layer that continues is its PRE-ReLU output: the tap itself
+                    pass
+                if all(t is None for t in (chain, pooled, add_post, add_pre, aff_post, aff_pre)):
                     g_in = None
                 else:
-                    g_in = ops.grad_join_g8(m["shape"], chain, pooled, gate, add_post, add_pre)
+                    # the tap of a post capture is relu(y) when y is the saved pre-ReLU output of a pre-captured layer
+                    aff_x = None
+                    if aff_post is not None:
+                        aff_x = y if idx not in ctx.pre_idx else torch.relu(y)
+                    elif aff_pre is not None:
+                        aff_x = y
+                    g_in = ops.grad_join_g8(m["shape"], chain, pooled, gate, add_post, add_pre, aff_x, aff_post, aff_pre)
             if g_in is None:                                    # no loss above this layer
                 kind, g = None, None
                 continue

@@ -33,6 +33,11 @@ struct JoinParams {
   const float* x;
   const float* add_post;
   const float* add_pre;
+  // the loss gradient as per-plane affine coefficients [n * c][4] = (k0, k1, mean, -): k0 + k1 * (t - mean) of the
+  // tap t = aff_x (st_meanstd_loss_bwd_coeffs) in place of a materialised add_post / add_pre tensor
+  const float* aff_x;
+  const float* aff_post;
+  const float* aff_pre;
   u32x4* out;
   int c, h, w;
   long long total;   // threads' worth of work items
@@ -59,30 +64,43 @@ __global__ __launch_bounds__(256) void grad_join_kernel(JoinParams p) {
     const long long b = t / cgs;
     const long long base = (b * p.c + cg * 8) * hw + pix;
     float v[PX][8];
+    const bool has_post = p.add_post || p.aff_post, has_pre = p.add_pre || p.aff_pre;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long long off = base + j * hw;
-      float a[PX], g[PX], q[PX], r[PX];
+      float a[PX], g[PX], q[PX], r[PX], t[PX];
       if constexpr (PX == 4) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 a4 = p.chain ? *reinterpret_cast<const f32x4*>(p.chain + off) : z;
         const f32x4 q4 = p.add_post ? *reinterpret_cast<const f32x4*>(p.add_post + off) : z;
         const f32x4 g4 = p.x ? *reinterpret_cast<const f32x4*>(p.x + off) : z;
         const f32x4 r4 = p.add_pre ? *reinterpret_cast<const f32x4*>(p.add_pre + off) : z;
+        const f32x4 t4 = p.aff_x ? (p.aff_x == p.x ? g4 : *reinterpret_cast<const f32x4*>(p.aff_x + off)) : z;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { a[k] = a4[k]; q[k] = q4[k]; g[k] = g4[k]; r[k] = r4[k]; }
+        for (int k = 0; k < 4; ++k) { a[k] = a4[k]; q[k] = q4[k]; g[k] = g4[k]; r[k] = r4[k]; t[k] = t4[k]; }
       } else {
         a[0] = p.chain ? p.chain[off] : 0.f;
         q[0] = p.add_post ? p.add_post[off] : 0.f;
         g[0] = p.x ? p.x[off] : 0.f;
         r[0] = p.add_pre ? p.add_pre[off] : 0.f;
+        t[0] = p.aff_x ? p.aff_x[off] : 0.f;
+      }
+      if (p.aff_post) {      // meanstd_loss_bwd_kernel's expression on its three per-plane scalars
+        const f32x4 cf = reinterpret_cast<const f32x4*>(p.aff_post)[b * p.c + cg * 8 + j];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) q[k] = cf[0] + cf[1] * (t[k] - cf[2]);
+      }
+      if (p.aff_pre) {
+        const f32x4 cf = reinterpret_cast<const f32x4*>(p.aff_pre)[b * p.c + cg * 8 + j];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) r[k] = cf[0] + cf[1] * (t[k] - cf[2]);
       }
 #pragma unroll
       for (int k = 0; k < PX; ++k) {
         float s = a[k];
-        if (p.add_post) s = p.chain ? s + q[k] : q[k];
+        if (has_post) s = p.chain ? s + q[k] : q[k];
         if (p.x) s = g[k] > 0.f ? s : 0.f;
-        if (p.add_pre) s = (p.chain || p.add_post) ? s + r[k] : r[k];
+        if (has_pre) s = (p.chain || has_post) ? s + r[k] : r[k];
         v[k][j] = s;
       }
     }
@@ -131,12 +149,23 @@ __global__ __launch_bounds__(256) void grad_join_pool_kernel(JoinParams p) {
         const f32x2 r1 = *reinterpret_cast<const f32x2*>(p.add_pre + off + p.w);
         r[0] = r0[0]; r[1] = r0[1]; r[2] = r1[0]; r[3] = r1[1];
       }
+      // affine loss gradients of the tap (here always the pool's input x itself: the entry point checks aff_x == x)
+      if (p.aff_post) {
+        const f32x4 cf = reinterpret_cast<const f32x4*>(p.aff_post)[plane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = cf[0] + cf[1] * (xs[k] - cf[2]);
+      }
+      if (p.aff_pre) {
+        const f32x4 cf = reinterpret_cast<const f32x4*>(p.aff_pre)[plane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = cf[0] + cf[1] * (xs[k] - cf[2]);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float s = arg == k ? g : 0.f;
-        if (p.add_post) s += q[k];
+        if (p.add_post || p.aff_post) s += q[k];
         s = xs[k] > 0.f ? s : 0.f;
-        if (p.add_pre) s += r[k];
+        if (p.add_pre || p.aff_pre) s += r[k];
         v[k][j] = s;
       }
     }
@@ -182,22 +211,27 @@ inline int grid_for(long long total) {
 
 }  // namespace
 
-extern "C" int st_grad_join_g8(const float* chain, const float* chain_pooled, const float* x_gate,
-                               const float* add_post, const float* add_pre, void* out_g8, int n, int c, int h,
-                               int w, st_stream_t stream) {
+static int grad_join_impl(const float* chain, const float* chain_pooled, const float* x_gate, const float* add_post,
+                          const float* add_pre, const float* aff_x, const float* aff_post, const float* aff_pre,
+                          void* out_g8, int n, int c, int h, int w, st_stream_t stream) {
   ST_REQUIRE(out_g8, "st_grad_join_g8: null output");
   ST_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && c % 8 == 0, "st_grad_join_g8: bad dims n=%d c=%d h=%d w=%d (c %% 8 == 0)",
              n, c, h, w);
   ST_REQUIRE(!(chain && chain_pooled), "st_grad_join_g8: chain and chain_pooled exclude each other");
-  ST_REQUIRE(chain || chain_pooled || add_post || add_pre, "st_grad_join_g8: no gradient source");
-  ST_REQUIRE(reinterpret_cast<uintptr_t>(out_g8) % 16 == 0, "st_grad_join_g8: out_g8 must be 16-byte aligned");
+  ST_REQUIRE(chain || chain_pooled || add_post || add_pre || aff_post || aff_pre, "st_grad_join_g8: no gradient source");
+  ST_REQUIRE(!(add_post && aff_post) && !(add_pre && aff_pre), "st_grad_join_g8: a loss gradient is a tensor OR coefficients");
+  ST_REQUIRE(!(aff_post || aff_pre) || aff_x, "st_grad_join_g8_affine: coefficients need the tap tensor aff_x");
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(out_g8) % 16 == 0 && reinterpret_cast<uintptr_t>(aff_post) % 16 == 0 &&
+             reinterpret_cast<uintptr_t>(aff_pre) % 16 == 0, "st_grad_join_g8: out_g8 / coefficients must be 16-byte aligned");
   JoinParams p;
   p.chain = chain; p.chain_pooled = chain_pooled; p.x = x_gate; p.add_post = add_post; p.add_pre = add_pre;
+  p.aff_x = aff_x; p.aff_post = aff_post; p.aff_pre = aff_pre;
   p.out = (u32x4*)out_g8; p.c = c; p.h = h; p.w = w;
   hipStream_t s = (hipStream_t)stream;
   const long long hw = (long long)h * w;
   if (chain_pooled) {
     ST_REQUIRE(x_gate, "st_grad_join_g8: chain_pooled needs the pool's input in x_gate");
+    ST_REQUIRE(!aff_x || aff_x == x_gate, "st_grad_join_g8_affine: with chain_pooled the tap is the pool's input");
     ST_REQUIRE(h % 2 == 0 && w % 2 == 0, "st_grad_join_g8: chain_pooled needs even h, w (got %dx%d)", h, w);
     for (const float* q : {x_gate, add_post, add_pre})
       ST_REQUIRE(reinterpret_cast<uintptr_t>(q) % 8 == 0, "st_grad_join_g8: 8-byte aligned fp32 tensors expected");
@@ -206,7 +240,7 @@ extern "C" int st_grad_join_g8(const float* chain, const float* chain_pooled, co
     return st::check_launch("st_grad_join_g8");
   }
   bool vec = hw % 4 == 0;
-  for (const float* q : {chain, x_gate, add_post, add_pre}) vec = vec && reinterpret_cast<uintptr_t>(q) % 16 == 0;
+  for (const float* q : {chain, x_gate, add_post, add_pre, aff_x}) vec = vec && reinterpret_cast<uintptr_t>(q) % 16 == 0;
   if (vec) {
     p.total = (long long)n * (c / 8) * (hw / 4);
     hipLaunchKernelGGL(grad_join_kernel<4>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
@@ -215,6 +249,21 @@ extern "C" int st_grad_join_g8(const float* chain, const float* chain_pooled, co
     hipLaunchKernelGGL(grad_join_kernel<1>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
   }
   return st::check_launch("st_grad_join_g8");
+}
+
+extern "C" int st_grad_join_g8(const float* chain, const float* chain_pooled, const float* x_gate,
+                               const float* add_post, const float* add_pre, void* out_g8, int n, int c, int h,
+                               int w, st_stream_t stream) {
+  return grad_join_impl(chain, chain_pooled, x_gate, add_post, add_pre, nullptr, nullptr, nullptr, out_g8, n, c, h, w,
+                        stream);
+}
+
+extern "C" int st_grad_join_g8_affine(const float* chain, const float* chain_pooled, const float* x_gate,
+                                      const float* add_post, const float* add_pre, const float* aff_x,
+                                      const float* aff_post, const float* aff_pre, void* out_g8, int n, int c, int h,
+                                      int w, st_stream_t stream) {
+  return grad_join_impl(chain, chain_pooled, x_gate, add_post, add_pre, aff_x, aff_post, aff_pre, out_g8, n, c, h, w,
+                        stream);
 }
 
 extern "C" int st_maxpool2x2_fwd_g8(const float* x, void* y_g8, int n, int c, int h, int w, st_stream_t stream) {

@@ -333,7 +333,38 @@ __global__ __launch_bounds__(NT) void meanstd_loss_bwd_kernel(const float* __res
   }
 }
 
+// The per-plane scalars of meanstd_loss_bwd_kernel -- (k0, k1, mean, 0), the SAME expressions -- for a consumer that
+// evaluates the gradient k0 + k1 * (x - mean) itself while it reads x anyway (st_grad_join_g8_affine).
+__global__ __launch_bounds__(256) void meanstd_loss_coeffs_kernel(const float* __restrict__ ma,
+                                                                 const float* __restrict__ sa,
+                                                                 const float* __restrict__ mb,
+                                                                 const float* __restrict__ sb,
+                                                                 const float* __restrict__ gout, float scale,
+                                                                 float* __restrict__ coeffs, int planes, int hw) {
+  const int plane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (plane >= planes) return;
+  const float c = scale * (gout ? gout[0] : 1.f) * 2.f / float(planes);
+  const float mean = ma[plane], sd = sa[plane];
+  const float k0 = c * (mean - mb[plane]) / float(hw);
+  const float k1 = c * (sd - sb[plane]) / (float(hw - 1) * sd);
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 o;
+  o[0] = k0; o[1] = k1; o[2] = mean; o[3] = 0.f;
+  reinterpret_cast<f4*>(coeffs)[plane] = o;
+}
+
 }  // namespace
+
+extern "C" int st_meanstd_loss_bwd_coeffs(const float* mean_a, const float* std_a, const float* mean_b,
+                                          const float* std_b, const float* gout, float scale, float* coeffs,
+                                          int planes, int hw, st_stream_t stream) {
+  ST_REQUIRE(mean_a && std_a && mean_b && std_b && coeffs, "st_meanstd_loss_bwd_coeffs: null pointer");
+  ST_REQUIRE(planes > 0 && hw > 1, "st_meanstd_loss_bwd_coeffs: planes=%d hw=%d", planes, hw);
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(coeffs) % 16 == 0, "st_meanstd_loss_bwd_coeffs: coeffs must be 16-byte aligned");
+  hipLaunchKernelGGL(meanstd_loss_coeffs_kernel, dim3(st::cdiv(planes, 256)), dim3(256), 0, (hipStream_t)stream, mean_a,
+                     std_a, mean_b, std_b, gout, scale, coeffs, planes, hw);
+  return st::check_launch("st_meanstd_loss_bwd_coeffs");
+}
 
 extern "C" size_t st_reduce_workspace_bytes(void) { return size_t(2) * MAX_PARTS * sizeof(float); }
 

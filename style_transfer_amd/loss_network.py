@@ -195,12 +195,23 @@ class VGG19FeatureExtractor(nn.Module):
         keys = VGGChainFunction.keys(self.layout, last_all, pre, post)
         outs = dict(zip(keys, VGGChainFunction.apply(x, self, last_all, frozenset(pre), frozenset(post))))
 
-        def pick(s, i):
+        def key_of(s, i):
             if i == max(s) and self.layout[i][0] == "conv":
-                return outs[("pre", i)]
+                return ("pre", i)
             # a post-ReLU capture belongs to the conv unit it sits in (conv index or its ReLU's index)
-            return outs[("post", i - 1 if self.layout[i][0] == "relu" else i)]
-        return [[pick(s, i) for i in s] for s in sets]
+            return ("post", i - 1 if self.layout[i][0] == "relu" else i)
+        # taps with exactly ONE consumer among the sets (and not a pool output) may receive their loss gradient as
+        # per-plane affine coefficients (autograd_vgg.lazy_affine_grad; AdaINStyleLoss uses it)
+        uses: Dict[tuple, int] = {}
+        for s in sets:
+            for i in s:
+                uses[key_of(s, i)] = uses.get(key_of(s, i), 0) + 1
+        for k, t in outs.items():
+            if self.AFFINE_TAPS and uses.get(k, 0) == 1 and self.layout[k[1]][0] == "conv":
+                t._st_chain_tap = True
+        return [[outs[key_of(s, i)] for i in s] for s in sets]
+
+    AFFINE_TAPS = os.environ.get("ST_NO_AFFINE_TAPS") is None
 
     def _forward_multi_g8(self, x, sets, last_all, need_pre, compute):
         """forward_multi without gradients in a bf16 compute mode (the passes over the content and style ORIGINALS,

@@ -89,6 +89,26 @@ class _MeanStdLossFunction(torch.autograd.Function):
         return dx, None
 
 
+class _MeanStdLossTapFunction(torch.autograd.Function):
+    """_MeanStdLossFunction for an input that is a loss TAP of the bf16 VGG chain (autograd_vgg.VGGChainFunction): the
+    gradient w.r.t. the tap is k0 + k1 * (x - mean) per (image, channel) plane, and the chain's join kernel reads the
+    tap anyway -- so the backward hands over the per-plane coefficients (autograd_vgg.lazy_affine_grad) instead of
+    writing an [n, c, h, w] fp32 tensor that the join would read back: 12 bytes per tap element less HBM traffic
+    (0.6 ms of a 15 ms bf16 step at batch 8, 512 x 512).  Same fp32 expression: identical values."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        out = _MeanStdLossFunction.forward(ctx, x, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .autograd_vgg import lazy_affine_grad
+        x, ma, sa, mb, sb = ctx.saved_tensors
+        coeffs = ops.meanstd_loss_coeffs(ma, sa, mb, sb, g, int(x.shape[2] * x.shape[3]))
+        return lazy_affine_grad(x, coeffs), None
+
+
 class AdaINStyleLoss(nn.Module):
     """losses.py:14-39: MSE of channel means + MSE of channel stds (unbiased var + 1e-5)."""
 
@@ -100,6 +120,8 @@ class AdaINStyleLoss(nn.Module):
 
     def calc_style_loss(self, input, target):
         assert (input.size() == target.size())
+        if getattr(input, "_st_chain_tap", False) and input.is_contiguous():
+            return _MeanStdLossTapFunction.apply(input, target.detach().contiguous())
         return _MeanStdLossFunction.apply(input.contiguous(), target.detach().contiguous())
 
     def forward(self, input, target):

@@ -419,22 +419,48 @@ def wgrad_pre_ok(n: int, cout: int, cin: int, h: int, w: int) -> bool:
 
 def grad_join_g8(shape, chain: Optional[torch.Tensor] = None, chain_pooled: Optional[torch.Tensor] = None,
                  x_gate: Optional[torch.Tensor] = None, add_post: Optional[torch.Tensor] = None,
-                 add_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 add_pre: Optional[torch.Tensor] = None, aff_x: Optional[torch.Tensor] = None,
+                 aff_post: Optional[torch.Tensor] = None, aff_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
     """G8 bf16 of ``[x_gate > 0] * (chain + add_post) + add_pre`` for an fp32 NCHW ``shape`` (st_grad_join_g8);
-    ``chain_pooled`` instead of ``chain``: the gradient w.r.t. maxpool2x2_floor(x_gate), routed through the pool."""
+    ``chain_pooled`` instead of ``chain``: the gradient w.r.t. maxpool2x2_floor(x_gate), routed through the pool.
+    ``aff_post`` / ``aff_pre``: a loss gradient as per-plane coefficients [n * c, 4] (meanstd_loss_coeffs) of the tap
+    ``aff_x`` in place of the tensor ``add_post`` / ``add_pre`` (st_grad_join_g8_affine)."""
     lib = _lib.load()
     n, c, h, w = (int(v) for v in shape)
-    ref = next(t for t in (chain, chain_pooled, x_gate, add_post, add_pre) if t is not None)
-    for name, t in (("chain", chain), ("x_gate", x_gate), ("add_post", add_post), ("add_pre", add_pre)):
+    ref = next(t for t in (chain, chain_pooled, x_gate, add_post, add_pre, aff_x) if t is not None)
+    for name, t in (("chain", chain), ("x_gate", x_gate), ("add_post", add_post), ("add_pre", add_pre), ("aff_x", aff_x)):
         assert t is None or tuple(t.shape) == (n, c, h, w), f"{name}: shape {tuple(t.shape)} != {(n, c, h, w)}"
     assert chain_pooled is None or tuple(chain_pooled.shape) == (n, c, h // 2, w // 2)
+    for name, t in (("aff_post", aff_post), ("aff_pre", aff_pre)):
+        assert t is None or (tuple(t.shape) == (n * c, 4) and aff_x is not None), f"{name}: [n * c, 4] coefficients + aff_x"
     out = torch.empty((n, c // 8, h, w, 8), dtype=torch.bfloat16, device=ref.device)
     ptr = lambda t, name: _lib.dev_ptr(t, name) if t is not None else None      # noqa: E731
-    _lib.check(lib.st_grad_join_g8(ptr(chain, "chain"), ptr(chain_pooled, "chain_pooled"), ptr(x_gate, "x_gate"),
-                                   ptr(add_post, "add_post"), ptr(add_pre, "add_pre"),
-                                   _lib.dev_ptr(out, "out", torch.bfloat16), n, c, h, w, _lib.stream_ptr()),
-               "st_grad_join_g8")
+    if aff_post is None and aff_pre is None:
+        _lib.check(lib.st_grad_join_g8(ptr(chain, "chain"), ptr(chain_pooled, "chain_pooled"), ptr(x_gate, "x_gate"),
+                                       ptr(add_post, "add_post"), ptr(add_pre, "add_pre"),
+                                       _lib.dev_ptr(out, "out", torch.bfloat16), n, c, h, w, _lib.stream_ptr()),
+                   "st_grad_join_g8")
+    else:
+        _lib.check(lib.st_grad_join_g8_affine(ptr(chain, "chain"), ptr(chain_pooled, "chain_pooled"), ptr(x_gate, "x_gate"),
+                                              ptr(add_post, "add_post"), ptr(add_pre, "add_pre"), ptr(aff_x, "aff_x"),
+                                              ptr(aff_post, "aff_post"), ptr(aff_pre, "aff_pre"),
+                                              _lib.dev_ptr(out, "out", torch.bfloat16), n, c, h, w, _lib.stream_ptr()),
+                   "st_grad_join_g8_affine")
     return out
+
+
+def meanstd_loss_coeffs(ma, sa, mb, sb, gout: torch.Tensor, hw: int) -> torch.Tensor:
+    """[planes, 4] = (k0, k1, mean, 0) with d AdaINStyleLoss / d x = k0 + k1 * (x - mean) per (image, channel) plane
+    (st_meanstd_loss_bwd_coeffs: st_meanstd_loss_bwd's own per-plane scalars)."""
+    lib = _lib.load()
+    planes = int(ma.numel())
+    coeffs = torch.empty((planes, 4), dtype=torch.float32, device=ma.device)
+    g = gout.contiguous().reshape(1)
+    _lib.check(lib.st_meanstd_loss_bwd_coeffs(_lib.dev_ptr(ma, "ma"), _lib.dev_ptr(sa, "sa"), _lib.dev_ptr(mb, "mb"),
+                                              _lib.dev_ptr(sb, "sb"), _lib.dev_ptr(g, "gout"), 1.0,
+                                              _lib.dev_ptr(coeffs, "coeffs"), planes, int(hw), _lib.stream_ptr()),
+               "st_meanstd_loss_bwd_coeffs")
+    return coeffs
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, y_gate: Optional[torch.Tensor], want_bias: bool = True,

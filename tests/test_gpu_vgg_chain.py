@@ -190,3 +190,77 @@ def test_no_grad_g8_pass_with_the_pool_written_in_g8():
         net.GRAD_CHAIN = True
     for a, b in zip([t for s in got for t in s], [t for s in ref for t in s]):
         assert torch.equal(a, b.detach())
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 32, 48), (1, 8, 7, 9), (1, 128, 64, 64)])
+@pytest.mark.parametrize("terms", ["post", "pre", "chain+post", "pooled+post+pre", "chain+post-tensor+pre"])
+def test_grad_join_with_affine_loss_coefficients(ops, n, c, h, w, terms):
+    """st_grad_join_g8_affine: the mean/std loss gradient as (k0, k1, mean) per plane, evaluated inside the join, is
+    the tensor st_meanstd_loss_bwd writes -- same fp32 expression, so the G8 results are the same bits."""
+    from style_transfer_amd import losses
+    shape = (n, c, h, w)
+    x = torch.relu(_rand(shape, 11)) if "pooled" in terms else _rand(shape, 11)
+    target = _rand(shape, 12, 1.5) + 0.25
+    tap = x.clone().requires_grad_(True)
+    (losses.AdaINStyleLoss()(tap, target) * 3.5).backward()          # the tensor form, g = 3.5
+    dense = tap.grad
+    ma, sa = ops.mean_std(x, 1e-5)
+    mb, sb = ops.mean_std(target, 1e-5)
+    coeffs = ops.meanstd_loss_coeffs(ma, sa, mb, sb, torch.tensor(3.5, device="cuda"), h * w)
+    assert tuple(coeffs.shape) == (n * c, 4) and torch.equal(coeffs[:, 2], ma.reshape(-1))
+    chain = _rand(shape, 13) if "chain" in terms else None
+    pooled = _rand((n, c, h // 2, w // 2), 14) if "pooled" in terms else None
+    other = _rand(shape, 15)
+    kw = dict(chain=chain, chain_pooled=pooled, x_gate=x)
+    if terms == "post":
+        want = ops.grad_join_g8(shape, add_post=dense, **kw)
+        got = ops.grad_join_g8(shape, aff_x=x, aff_post=coeffs, **kw)
+    elif terms == "pre":
+        want = ops.grad_join_g8(shape, add_pre=dense, **kw)
+        got = ops.grad_join_g8(shape, aff_x=x, aff_pre=coeffs, **kw)
+    elif terms == "chain+post":
+        want = ops.grad_join_g8(shape, add_post=dense, **kw)
+        got = ops.grad_join_g8(shape, aff_x=x, aff_post=coeffs, **kw)
+    elif terms == "pooled+post+pre":
+        want = ops.grad_join_g8(shape, add_post=dense, add_pre=other, **kw)
+        got = ops.grad_join_g8(shape, aff_x=x, aff_post=coeffs, add_pre=other, **kw)
+    else:                                                             # a tensor term beside an affine one
+        want = ops.grad_join_g8(shape, add_post=other, add_pre=dense, **kw)
+        got = ops.grad_join_g8(shape, add_post=other, aff_x=x, aff_pre=coeffs, **kw)
+    assert float(ops.from_g8(want).abs().max()) > 0
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 72, 88)])
+def test_affine_tap_handover_is_bit_identical_to_the_tensor_form(n, h, w):
+    """The CLI's loss taps with AdaINStyleLoss on them (trainer.py:446-457): coefficients handed to the join
+    (loss_network.AFFINE_TAPS) vs. the [n, c, h, w] loss-gradient tensors."""
+    from style_transfer_amd import losses, precision
+    sets = [[21], [2, 7, 14, 19, 25]]
+    net = _extractor(sets)
+    x0 = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(8)).cuda()
+    style = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(9)).cuda()
+    crit = losses.AdaINStyleLoss()
+
+    def run(affine):
+        net.AFFINE_TAPS = affine
+        x = x0.clone().requires_grad_(True)
+        with precision.compute_dtype("bf16"):
+            with torch.no_grad():
+                targets = net.forward_multi(style, sets)
+            outs = net.forward_multi(x, sets)
+            assert all(getattr(t, "_st_chain_tap", False) == affine for t in outs[1])
+            loss = (outs[0][0] - targets[0][0]).pow(2).mean()
+            for k, (a, b) in enumerate(zip(outs[1], targets[1])):
+                loss = loss + (0.5 + k) * crit(a, b)
+            loss.backward()
+        return loss.detach(), x.grad
+
+    try:
+        ref_loss, ref = run(False)
+        got_loss, got = run(True)
+    finally:
+        del net.AFFINE_TAPS                                            # back to the class default
+    assert float(ref.abs().max()) > 0
+    assert torch.equal(got_loss, ref_loss)
+    assert torch.equal(got, ref)
