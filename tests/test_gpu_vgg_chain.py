@@ -198,6 +198,8 @@ def test_grad_join_with_affine_loss_coefficients(ops, n, c, h, w, terms):
     """st_grad_join_g8_affine: the mean/std loss gradient as (k0, k1, mean) per plane, evaluated inside the join, is
     the tensor st_meanstd_loss_bwd writes -- same fp32 expression, so the G8 results are the same bits."""
     from style_transfer_amd import losses
+    if "pooled" in terms:
+        h, w = h + h % 2, w + w % 2                                   # the pooled form takes even sizes only
     shape = (n, c, h, w)
     x = torch.relu(_rand(shape, 11)) if "pooled" in terms else _rand(shape, 11)
     target = _rand(shape, 12, 1.5) + 0.25
