@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cstdint>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -61,6 +63,11 @@ struct WgradParams {
   const unsigned short* g16;   // [n][cout][H][W] bf16, gate applied
   const unsigned short* x16;   // [n][cin][H + 2][wp] bf16: pad (and x2 upsample) materialised, pixel gx at column gx + 8
   int wp;                      // row pitch of x16 in elements (multiple of 8)
+  // XCD-aware block order (1-D grid of gx * gy * roundup(nsplit, 8) blocks): workgroups are dealt round-robin to the
+  // 8 XCDs, each with its own L2.  With the plain (cin chunk, cout tile, split) grid the gx blocks that read the SAME
+  // dy tile sit on gx different XCDs and every L2 fetches it again; here all gx * gy blocks of one pixel range share
+  // an XCD, so dy and x leave HBM once.
+  int gx = 0, gy = 0;          // 0: plain 3-D grid
 };
 
 // BO_ output channels x CI_ input channels per block; BO_ / 32 channel tiles x (CI_ * 9 / 32) column tiles are
@@ -662,9 +669,17 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int c0 = blockIdx.x * CI_;
-  const int o0 = blockIdx.y * BO_;
-  const int split = blockIdx.z;
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if (p.gx > 0) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, gs = p.gx * p.gy;
+    const int g = k % gs;
+    split = (k / gs) * 8 + xcd;
+    bx = g % p.gx;
+    by = g / p.gx;
+    if (split >= p.nsplit) return;     // the whole block (padding of the split count to a multiple of 8)
+  }
+  const int c0 = bx * CI_;
+  const int o0 = by * BO_;
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
   const size_t xplane = size_t(p.H + 2) * p.wp;
@@ -978,12 +993,15 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
     }
     p.g16 = g16; p.x16 = x16; p.wp = wp;
     p.bias_slabs = nullptr;
+    p.gx = (int)grid.x; p.gy = (int)grid.y;
+    const dim3 sgrid(grid.x * grid.y * unsigned((pl.nsplit + 7) / 8 * 8));
     if (sbo == 64)
-      ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), grid, dim3(NTHREADS),
+      ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), sgrid, dim3(NTHREADS),
                         (bf::SShape<64, 64>::LDS), s, p);
     else
-      ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", (bf::conv3x3_wgrad_bf16s_kernel<128, 32>), grid, dim3(NTHREADS),
+      ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16", (bf::conv3x3_wgrad_bf16s_kernel<128, 32>), sgrid, dim3(NTHREADS),
                         (bf::SShape<128, 32>::LDS), s, p);
+    p.gx = p.gy = 0;
     int rc = st::check_launch("st_conv3x3_wgrad_bf16(staged)");
     if (rc != ST_OK) return rc;
     const long long nw = (long long)cout * cin * 9;
@@ -1067,11 +1085,14 @@ extern "C" int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g1
                        dim3(256), 0, s, (const float*)x, x16, (long long)n * cin, hin, win, H, W, wp, up, p.pad_zero);
   }
   p.g16 = (unsigned short*)g16; p.x16 = x16; p.wp = wp;
+  p.gx = (int)grid.x; p.gy = (int)grid.y;
+  const dim3 sgrid(grid.x * grid.y * unsigned((pl.nsplit + 7) / 8 * 8));
+  if (getenv("ST_WGRAD_NO_XCD")) { p.gx = p.gy = 0; }
   if (sbo == 64)
-    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), grid, dim3(NTHREADS),
+    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), p.gx ? sgrid : grid, dim3(NTHREADS),
                       (bf::SShape<64, 64>::LDS), s, p);
   else
-    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<128, 32>), grid, dim3(NTHREADS),
+    ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<128, 32>), p.gx ? sgrid : grid, dim3(NTHREADS),
                       (bf::SShape<128, 32>::LDS), s, p);
   int rc = st::check_launch("st_conv3x3_wgrad_bf16_pre");
   if (rc != ST_OK) return rc;
