@@ -30,12 +30,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/tra
     > /dev/null 2> "$O/train_bf16_stats.err"
 cp "$(find $S/trainbf -name '*kernel_stats.csv' | head -1)" "$O/train_bf16_512_kernel_stats.csv"
 
+# the two PMC passes run the headline shape only (fp32 + bf16 legs at B=16, 512^2; no 2048^2 leg, whose launches
+# of the same instantiations carry other byte counts and would move the per-launch average)
 echo "[5/6] PMC pass: FETCH_SIZE"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $S/fetch -o p -- \
-    python3 "$R/bench.py" --mode infer --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> "$O/pmc_fetch.err"
+    python3 "$R/bench.py" --mode infer --no-cpu-baseline --no-hires --no-aux --steps 3 --warmup 1 > /dev/null 2> "$O/pmc_fetch.err"
 echo "[6/6] PMC pass: WRITE_SIZE"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $S/write -o p -- \
-    python3 "$R/bench.py" --mode infer --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> "$O/pmc_write.err"
+    python3 "$R/bench.py" --mode infer --no-cpu-baseline --no-hires --no-aux --steps 3 --warmup 1 > /dev/null 2> "$O/pmc_write.err"
 python3 "$R/tools/pmc_hbm_csv.py" $S/fetch $S/write > "$O/bench_infer_pmc_hbm.csv"
 
 echo "[7] loss kernels (histogram, TV, covariance, mean/std, MSE): kernel stats + FETCH_SIZE / WRITE_SIZE passes"
