@@ -183,6 +183,13 @@ size_t st_conv3x3_wgrad_bf16_pre_workspace_bytes(int n, int cout, int cin, int h
 int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g16, const float* bias_slabs, int n_bias_slabs,
                               float* dw, float* dbias, float* workspace, int n, int cin, int hin, int win, int cout,
                               int upsample2x, int pad_mode, st_stream_t stream);
+/* Weight / bias gradient of the decoder's 3-output-channel top layer (generator.py:127-128; loss.backward() of
+ * trainer.py:472) when its input arrives in G8 [n][cin/8][hin][win][8] from the bf16 chain: st_conv3x3_wgrad's
+ * vector-ALU form for cout == 3 (fp32 dy [n][3][H][W], fp32 accumulation, fixed-order slab sums) reading the bf16
+ * activation directly -- the values the layer's forward multiplied.  cin % 8 == 0; workspace:
+ * st_conv3x3_wgrad_workspace_bytes(n, 3, cin, H, W); dbias may be NULL. */
+int st_conv3x3_wgrad_cout3_xg8(const void* x_g8, const float* dy, float* dw, float* dbias, float* workspace, int n,
+                               int cin, int hin, int win, int upsample2x, int pad_mode, st_stream_t stream);
 /* The gradient that reaches a CAPTURED layer output (a loss tap of trainer.py:446-457, fp32 NCHW) or the input of
  * a max pool, formed in one pass as the G8 operand of that layer's st_conv3x3_dgrad_bf16_g8:
  *     out_g8 = [x_gate > 0] * (chain + add_post) + add_pre

@@ -1,6 +1,8 @@
 """autograd Functions for the fused conv layer and the max pool (HIP forward + HIP backward)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -136,10 +138,10 @@ class DecoderChainFunction(torch.autograd.Function):
 class DecoderChainG8Function(torch.autograd.Function):
     """DecoderChainFunction for the bf16 compute mode with G8 hand-overs in BOTH directions.
 
-    Forward: generator._g8_chain's launches (fp32 in, G8 between the layers, bit-identical to the fp32-activation
-    kernels); the last ReLU layer writes fp32 because the 3-channel top layer's vector-ALU gradient kernels read
-    fp32.  The saved layer inputs are the G8 tensors: half the bytes, and already the bf16 values the weight
-    gradient rounds its input to.
+    Forward: generator._g8_chain's launches (fp32 in, G8 between ALL the layers, bit-identical to the fp32-activation
+    kernels; the 3-channel top layer's forward, its data gradient's gate and its vector-ALU weight gradient read the
+    G8 form too -- TOP_G8 = False keeps round 2's fp32 hand-over to the top layer for A/B).  The saved layer inputs
+    are the G8 tensors: half the bytes, and already the bf16 values the weight gradient rounds its input to.
 
     Backward, per layer from the top: ONE data-gradient call (ops.conv3x3_dgrad_g8_chain) takes the gated gradient
     in G8 (staged by LDS-DMA), folds the padded-domain result, applies the ReLU gate of the layer below from its G8
@@ -149,6 +151,8 @@ class DecoderChainG8Function(torch.autograd.Function):
     as DecoderChainFunction before the (identical) bf16 roundings; the bias gradient is summed in another (fixed)
     order.  Shapes outside the staged weight-gradient form use DecoderChainFunction (Decoder.forward decides).
     """
+
+    TOP_G8 = os.environ.get("ST_DEC_TOP_F32") is None
 
     @staticmethod
     def usable(x, specs, params) -> bool:
@@ -171,7 +175,8 @@ class DecoderChainG8Function(torch.autograd.Function):
             w, b = params[2 * i], params[2 * i + 1]
             wp = cache.get(key, w, False, "bf16")
             acts.append(ops.conv3x3_g8(acts[-1], wp, b.detach(), cout, upsample2x=up, pad_mode=ops.PAD_REPLICATE,
-                                       relu=relu, pool=False, y_g8=i < n_l - 2))
+                                       relu=relu, pool=False,
+                                       y_g8=i < n_l - (1 if DecoderChainG8Function.TOP_G8 else 2)))
         ctx.cache, ctx.specs = cache, specs
         ctx.save_for_backward(*acts[:-1], *params)
         return acts[-1]
@@ -193,7 +198,11 @@ class DecoderChainG8Function(torch.autograd.Function):
             if need_w or need_b:
                 direct = (getattr(ctx.cache, "direct_grads", False) and need_w and need_b and w.grad is not None
                           and b.grad is not None and w.grad.is_contiguous() and b.grad.is_contiguous())
-                if i == n - 1:         # 64 -> 3: fp32 dy, fp32 x, the vector-ALU kernel
+                if i == n - 1 and ops.is_g8(x_i):         # 64 -> 3: fp32 dy, G8 x, the vector-ALU kernel
+                    dw, db = ops.conv3x3_wgrad_cout3_g8(x_i, g, upsample2x=up, pad_mode=ops.PAD_REPLICATE,
+                                                        dw_out=w.grad if direct else None,
+                                                        db_out=b.grad if direct else None)
+                elif i == n - 1:       # ... fp32 x (TOP_G8 = False)
                     dw, db = ops.conv3x3_wgrad(x_i, g, None, want_bias=True, upsample2x=up,
                                                pad_mode=ops.PAD_REPLICATE, compute="bf16",
                                                dw_out=w.grad if direct else None, db_out=b.grad if direct else None)

@@ -431,7 +431,9 @@ int launch_cout_strip_w(const float* x, const float* wp, const float* bias, floa
 // fixed-order slab reduction of csrc/conv3x3_wgrad.hip sums.  Deterministic, no atomics.
 constexpr int WC = 4;
 
-template <int CO>
+// XG8: x is the G8 activation (bf16 [n][cin/8][hs][ws][8], the hand-over form of the bf16 decoder chain): the block's
+// WC = 4 channels are one half of a pixel's 16-byte unit, read as 8 bytes and widened to fp32 (exact).
+template <int CO, bool XG8 = false>
 __global__ __launch_bounds__(256) void wgrad_cout_small_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ygate,
     float* __restrict__ slabs, float* __restrict__ bias_slabs, int n, int cin, int hs, int ws, int H, int W,
@@ -475,9 +477,20 @@ __global__ __launch_bounds__(256) void wgrad_cout_small_kernel(
       if (up) { cy >>= 1; cx >>= 1; }
       loff[i] = unsigned(r * BLD + cc);
       smask[i] = (inb || !pad_zero) ? 0xffffffffu : 0u;
+      if constexpr (XG8) {
+        static_assert(WC == 4, "half a G8 unit");
+        const unsigned short* xg = reinterpret_cast<const unsigned short*>(x);
+        const size_t at = ((size_t(b) * (cin >> 3) + (c0 >> 3)) * plane_src + size_t(cy) * ws + cx) * 8 + (c0 & 7);
+        const uint2 v = *reinterpret_cast<const uint2*>(xg + at);
+        st_[0][i] = __uint_as_float(v.x << 16);
+        st_[1][i] = __uint_as_float(v.x & 0xffff0000u);
+        st_[2][i] = __uint_as_float(v.y << 16);
+        st_[3][i] = __uint_as_float(v.y & 0xffff0000u);
+      } else {
 #pragma unroll
-      for (int c = 0; c < WC; ++c)
-        st_[c][i] = x[(size_t(b) * cin + min(c0 + c, cin - 1)) * plane_src + size_t(cy) * ws + cx];
+        for (int c = 0; c < WC; ++c)
+          st_[c][i] = x[(size_t(b) * cin + min(c0 + c, cin - 1)) * plane_src + size_t(cy) * ws + cx];
+      }
     }
     // this thread's 4 pixels of the CO gradient planes (zero outside the image)
     float g[CO][4];
@@ -607,13 +620,17 @@ int wgrad_small_nsplit(int n, int cout, int cin, int H, int W) {
 }
 
 int wgrad_small_launch(const float* x, const float* dy, const float* ygate, float* slabs, float* bias_slabs, int n,
-                       int cin, int hs, int ws, int H, int W, int up, int pad_zero, hipStream_t s) {
+                       int cin, int hs, int ws, int H, int W, int up, int pad_zero, hipStream_t s, bool x_g8) {
   const int tiles_x = cdiv(W, BTW), tiles_y = cdiv(H, BTH);
   const int ntiles = n * tiles_x * tiles_y;
   const int nsplit = wgrad_small_nsplit(n, 3, cin, H, W);
   const int per = cdiv(ntiles, nsplit);
-  hipLaunchKernelGGL(wgrad_cout_small_kernel<3>, dim3(cdiv(cin, WC), nsplit), dim3(256), 0, s, x, dy, ygate, slabs,
-                     bias_slabs, n, cin, hs, ws, H, W, up, pad_zero, tiles_x, tiles_y, ntiles, per);
+  if (x_g8)     // cin % 8 == 0 checked by the caller
+    hipLaunchKernelGGL((wgrad_cout_small_kernel<3, true>), dim3(cdiv(cin, WC), nsplit), dim3(256), 0, s, x, dy, ygate,
+                       slabs, bias_slabs, n, cin, hs, ws, H, W, up, pad_zero, tiles_x, tiles_y, ntiles, per);
+  else
+    hipLaunchKernelGGL((wgrad_cout_small_kernel<3, false>), dim3(cdiv(cin, WC), nsplit), dim3(256), 0, s, x, dy, ygate,
+                       slabs, bias_slabs, n, cin, hs, ws, H, W, up, pad_zero, tiles_x, tiles_y, ntiles, per);
   return check_launch("st_conv3x3_wgrad(cout=3)");
 }
 

@@ -827,20 +827,20 @@ namespace st {
 // csrc/conv3x3_small.hip: vector-ALU weight gradient of the 3-output-channel layer
 int wgrad_small_nsplit(int n, int cout, int cin, int H, int W);
 int wgrad_small_launch(const float* x, const float* dy, const float* ygate, float* slabs, float* bias_slabs, int n,
-                       int cin, int hs, int ws, int H, int W, int up, int pad_zero, hipStream_t s);
+                       int cin, int hs, int ws, int H, int W, int up, int pad_zero, hipStream_t s, bool x_g8);
 }  // namespace st
 
 // cout == 3: the vector-ALU kernel writes its partial slabs, the fixed-order reduction below sums them
 static int wgrad_small(const float* x, const float* dy, const float* y_gate, float* dw, float* dbias,
                        float* workspace, int n, int cin, int hin, int win, int cout, int up, int pad_mode,
-                       hipStream_t s, bool* handled) {
+                       hipStream_t s, bool* handled, bool x_g8 = false) {
   const int H = hin << up, W = win << up;
   const int nsplit = st::wgrad_small_nsplit(n, cout, cin, H, W);
   *handled = nsplit > 0;
   if (!*handled) return ST_OK;
   float* bias_slabs = dbias ? workspace + size_t(nsplit) * cout * cin * 9 : nullptr;
   int rc = st::wgrad_small_launch(x, dy, y_gate, workspace, bias_slabs, n, cin, hin, win, H, W, up,
-                                  pad_mode == ST_PAD_ZERO, s);
+                                  pad_mode == ST_PAD_ZERO, s, x_g8);
   if (rc != ST_OK) return rc;
   const long long nw = (long long)cout * cin * 9;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)std::min<long long>(st::cdivll(nw, 256), 2048)),
@@ -860,6 +860,23 @@ extern "C" size_t st_conv3x3_wgrad_workspace_bytes(int n, int cout, int cin, int
                                make_plan(n, cout, cin, h, w, bf::TRB, bo, ci).nsplit,
                                st::wgrad_small_nsplit(n, cout, cin, h, w)});
   return size_t(nsplit) * (size_t(cout) * cin * 9 + cout) * sizeof(float);
+}
+
+extern "C" int st_conv3x3_wgrad_cout3_xg8(const void* x_g8, const float* dy, float* dw, float* dbias,
+                                          float* workspace, int n, int cin, int hin, int win, int upsample2x,
+                                          int pad_mode, st_stream_t stream) {
+  ST_REQUIRE(x_g8 && dy && dw && workspace, "st_conv3x3_wgrad_cout3_xg8: null pointer");
+  ST_REQUIRE(n > 0 && cin > 0 && cin % 8 == 0 && hin > 0 && win > 0,
+             "st_conv3x3_wgrad_cout3_xg8: bad dims n=%d cin=%d (multiple of 8) h=%d w=%d", n, cin, hin, win);
+  ST_REQUIRE(pad_mode == ST_PAD_REPLICATE || pad_mode == ST_PAD_ZERO, "st_conv3x3_wgrad_cout3_xg8: bad pad_mode %d",
+             pad_mode);
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(x_g8) % 16 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0,
+             "st_conv3x3_wgrad_cout3_xg8: x_g8 / dy must be 16-byte aligned");
+  bool handled = false;
+  const int rc = wgrad_small(reinterpret_cast<const float*>(x_g8), dy, nullptr, dw, dbias, workspace, n, cin, hin, win,
+                             3, upsample2x ? 1 : 0, pad_mode, (hipStream_t)stream, &handled, true);
+  ST_REQUIRE(handled, "st_conv3x3_wgrad_cout3_xg8: too many pixel tiles");
+  return rc;
 }
 
 extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_gate, float* dw,

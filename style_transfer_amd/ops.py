@@ -412,6 +412,27 @@ def conv3x3_wgrad_pre(x: torch.Tensor, g16: torch.Tensor, bias_slabs: Optional[t
     return dw, db
 
 
+def conv3x3_wgrad_cout3_g8(x_g8: torch.Tensor, dy: torch.Tensor, upsample2x: bool = False, pad_mode="replicate",
+                           dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    """(dW [3, cin, 3, 3], dbias [3]) of the 3-output-channel top layer from its G8 input and the fp32 ``dy``
+    (st_conv3x3_wgrad_cout3_xg8: the vector-ALU weight gradient reading the bf16 activation directly)."""
+    lib = _lib.load()
+    assert is_g8(x_g8)
+    n, cin, h, w = int(x_g8.shape[0]), int(x_g8.shape[1]) * 8, int(x_g8.shape[2]), int(x_g8.shape[3])
+    s = 2 if upsample2x else 1
+    assert tuple(dy.shape) == (n, 3, h * s, w * s) and dy.dtype == torch.float32, f"dy shape {tuple(dy.shape)}"
+    dw = dw_out if dw_out is not None else torch.empty((3, cin, 3, 3), dtype=torch.float32, device=dy.device)
+    db = db_out if db_out is not None else torch.empty((3,), dtype=torch.float32, device=dy.device)
+    assert tuple(dw.shape) == (3, cin, 3, 3) and tuple(db.shape) == (3,)
+    ws = torch.empty(lib.st_conv3x3_wgrad_workspace_bytes(n, 3, cin, h * s, w * s) // 4, dtype=torch.float32,
+                     device=dy.device)
+    _lib.check(lib.st_conv3x3_wgrad_cout3_xg8(
+        _lib.dev_ptr(x_g8, "x_g8", torch.bfloat16), _lib.dev_ptr(dy, "dy"), _lib.dev_ptr(dw, "dw"), _lib.dev_ptr(db, "db"),
+        _lib.dev_ptr(ws, "workspace"), n, cin, h, w, int(upsample2x), _pad_code(pad_mode), _lib.stream_ptr()),
+        "st_conv3x3_wgrad_cout3_xg8")
+    return dw, db
+
+
 def wgrad_pre_ok(n: int, cout: int, cin: int, h: int, w: int) -> bool:
     """Is [n, cout, h, w] (conv-input dims after the upsample) a shape of the staged weight-gradient form?"""
     return _lib.load().st_conv3x3_wgrad_bf16_pre_workspace_bytes(n, cout, cin, h, w) > 0

@@ -35,6 +35,8 @@ def _both(dy, wpt, cin, up, gate):
 # (n, k = the layer's output channels, c = its input channels, h, w of the conv input, upsample, dy form, gate form)
 CASES = [
     (2, 3, 64, 32, 64, False, "f32", "f32"),       # the top layer: fp32 dy of 3 channels, fp32 gate
+    (2, 3, 64, 64, 96, False, "f32", "g8"),        # the top layer with its input handed over in G8 (TOP_G8)
+    (1, 3, 64, 40, 32, False, "f32", "g8"),        # ... ragged tile rows
     (2, 64, 64, 16, 64, True, "g8", "g8"),         # 64 -> 64 under the upsample
     (1, 64, 128, 8, 32, False, "g8", "g8"),        # 128 -> 64
     (2, 128, 128, 16, 32, True, "g8", "g8"),       # 128 -> 128 under the upsample, one tile column

@@ -4,7 +4,8 @@ fp32-activation chain (DecoderChainFunction, pinned to the same-rounding oracle 
 
 Output, input gradient and weight gradients must be BIT-IDENTICAL (a G8 / bf16 hand-over is the rounding the
 consumer's staging applies to the fp32 form anyway; fold, gate and GEMMs do the same fp32 arithmetic); the bias
-gradients are summed in another fixed order and agree to fp32 rounding.
+gradients are summed in another fixed order and agree to fp32 rounding.  One stated exception: with the G8 hand-over
+to the 3-channel top layer (TOP_G8, round 3) that layer's vector-ALU weight gradient sees the bf16 activation.
 """
 import pytest
 import torch
@@ -32,9 +33,28 @@ def _run(dec, x0, gy, chain):
     return y.detach(), x.grad, [p.grad.clone() for p in dec.parameters()]
 
 
+@pytest.mark.parametrize("n,cin,h,w,up,pad", [(2, 64, 32, 64, False, "replicate"), (1, 64, 19, 37, False, "replicate"),
+                                               (2, 16, 8, 24, True, "replicate"), (1, 8, 5, 5, False, "zero")])
+def test_top_layer_weight_gradient_from_a_g8_input(n, cin, h, w, up, pad):
+    """st_conv3x3_wgrad_cout3_xg8 reads the G8 activation; the fp32 entry point on the same (bf16) values does the
+    same fp32 arithmetic in the same order: bit-identical."""
+    from style_transfer_amd import ops
+    g = torch.Generator().manual_seed(n + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g).cuda()
+    s = 2 if up else 1
+    dy = torch.randn(n, 3, h * s, w * s, generator=g).cuda()
+    xg = ops.to_g8(x)
+    dw, db = ops.conv3x3_wgrad_cout3_g8(xg, dy, upsample2x=up, pad_mode=pad)
+    dw0, db0 = ops.conv3x3_wgrad(ops.from_g8(xg), dy, None, want_bias=True, upsample2x=up, pad_mode=pad, compute="bf16")
+    assert float(dw0.abs().max()) > 0
+    assert torch.equal(dw, dw0) and torch.equal(db, db0)
+
+
+@pytest.mark.parametrize("top_g8", [False, True])
 @pytest.mark.parametrize("n,h,w", [(2, 4, 32), (1, 8, 64), (2, 32, 32)])
-def test_decoder_g8_chain_matches_the_fp32_activation_chain(n, h, w):
+def test_decoder_g8_chain_matches_the_fp32_activation_chain(n, h, w, top_g8, monkeypatch):
     from style_transfer_amd.autograd_conv import DecoderChainG8Function
+    monkeypatch.setattr(DecoderChainG8Function, "TOP_G8", top_g8)
     dec = _decoder()
     g = torch.Generator().manual_seed(3)
     x0 = torch.relu(torch.randn(n, 512, h, w, generator=g)).cuda()
@@ -55,7 +75,14 @@ def test_decoder_g8_chain_matches_the_fp32_activation_chain(n, h, w):
     assert float(dx0.abs().max()) > 0
     assert torch.equal(dx1, dx0)
     for k, (a, b) in enumerate(zip(gr1, gr0)):
-        if a.dim() == 4:
+        if a.dim() == 4 and top_g8 and k == len(gr1) - 2:
+            # the 64 -> 3 layer's weight gradient multiplies dy with the bf16 values its forward multiplied (the G8
+            # input) where the fp32-activation chain multiplies with the unrounded fp32 activation: bf16 rounding of
+            # one operand, <= 2^-9 per product; with a random-sign dy the sum cancels, so relative to the SUM it is
+            # more (measured 1.5e-3 ... 5.6e-3 on these shapes).  The bit-level check of the kernel is
+            # test_top_layer_weight_gradient_from_a_g8_input.
+            assert float((a - b).norm() / b.norm()) < 2e-2, f"top-layer weight gradient {float((a - b).norm() / b.norm())}"
+        elif a.dim() == 4:
             assert torch.equal(a, b), f"weight gradient {k}"
         else:
             torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))

@@ -168,8 +168,12 @@ def test_bf16_g8_training_chains_at_the_configs3_size():
     for a, b in zip(got[0], ref[0]):
         assert torch.equal(a, b)
     assert float(ref[1].abs().max()) > 0 and torch.equal(got[1], ref[1])
-    for a, b in zip(got[2], ref[2]):
-        if a.dim() == 4:
+    for k, (a, b) in enumerate(zip(got[2], ref[2])):
+        if a.dim() == 4 and k == len(got[2]) - 2:
+            # the 64 -> 3 layer's vector-ALU weight gradient reads its input in G8: bf16 rounding of one operand against
+            # the fp32-activation chain (bit-level check of that kernel: tests/test_gpu_decoder_chain_g8.py)
+            assert float((a - b).norm() / b.norm()) < 5e-3
+        elif a.dim() == 4:
             assert torch.equal(a, b)
         else:
             torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))
