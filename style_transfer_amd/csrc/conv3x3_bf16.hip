@@ -301,9 +301,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         }                                                                                  \
       } else {                                                                             \
         _Pragma("unroll") for (int i = 0; i < C::NP; ++i) {                                \
-          const int cg = min((chunk_) * KC + half_[i] * 8 + j, p.cin - 1);                 \
-          xr[i][j] = xb[size_t(cg) * plane_src + soff[i]];                                 \
-          if (GATE) gr[i][j] = gb[size_t(cg) * plane_src + soff[i]];                       \
+          const int cg = (chunk_) * KC + half_[i] * 8 + j;                                 \
+          /* channels past the end are not requested at all (3-channel layers: 13 of 16) */ \
+          xr[i][j] = cg < p.cin ? xb[size_t(cg) * plane_src + soff[i]] : 0.f;              \
+          if (GATE) gr[i][j] = cg < p.cin ? gb[size_t(cg) * plane_src + soff[i]] : 0.f;    \
         }                                                                                  \
       }                                                                                    \
     }                                                                                      \
