@@ -68,6 +68,7 @@ struct WgradParams {
   // dy tile sit on gx different XCDs and every L2 fetches it again; here all gx * gy blocks of one pixel range share
   // an XCD, so dy and x leave HBM once.
   int gx = 0, gy = 0;          // 0: plain 3-D grid
+  int ablate = 0;              // TEMP
 };
 
 // BO_ output channels x CI_ input channels per block; BO_ / 32 channel tiles x (CI_ * 9 / 32) column tiles are
@@ -701,9 +702,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
     bOff[jt] = (tap % 3) * S::XCOPY + c * X_CH_B + (tap / 3) * X_ROW_B + lh * 16;
   }
 
-  u32x4 gv[S::NGS_], xv[S::NXS_];
-  unsigned xl[S::NXS_], xr2[S::NXS_];
-  auto load = [&](int t) {
+  // Two register sets and barriers that do NOT drain vmcnt: the global loads of tile t + 2 are issued while tile t is
+  // multiplied and stay in flight across the two barriers of tile t + 1.  (__syncthreads() waits for vmcnt(0): with it
+  // a load had one MFMA phase, ~1.3 us, to arrive whatever the prefetch distance, and the kernel ran at load latency.)
+  struct Stage {
+    u32x4 gv[S::NGS_], xv[S::NXS_];
+    unsigned xl[S::NXS_];
+  };
+  Stage st0, st1;
+#define ST_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  auto load = [&](Stage& r, int t) {
     int rem = t;
     const int tx = rem % p.tiles_x;
     rem /= p.tiles_x;
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
       const int g = min(tid + i * NTHREADS, S::NG - 1);
       const int seg = g >> 2, q = g & 3;                         // seg = channel * 4 + tile row
       const int o = min(o0 + (seg >> 2), p.cout - 1);
-      gv[i] = *reinterpret_cast<const u32x4*>(p.g16 + (size_t(b) * p.cout + o) * gplane +
+      r.gv[i] = *reinterpret_cast<const u32x4*>(p.g16 + (size_t(b) * p.cout + o) * gplane +
                                               size_t(y0 + (seg & 3)) * p.W + x0 + q * 8);
     }
 #pragma unroll
@@ -724,18 +732,23 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
       const int xq = it & 3, xr = (it >> 2) % HRB, xc = it / (4 * HRB);
       const unsigned short* row = p.x16 + (size_t(b) * p.cin + min(c0 + xc, p.cin - 1)) * xplane +
                                   size_t(y0 + xr) * p.wp + XPAD + x0 + xq * 8;
-      xv[i] = *reinterpret_cast<const u32x4*>(row);
-      xl[i] = *reinterpret_cast<const unsigned*>(row - 2);
-      xr2[i] = *reinterpret_cast<const unsigned*>(row + 8);
+      r.xv[i] = *reinterpret_cast<const u32x4*>(row);
+      // One halo dword per item instead of two neighbour dwords: the four lanes xq = 0..3 of a row hold consecutive
+      // 8-pixel groups, so the left / right neighbour pixels of the inner groups come from the adjacent LANE at store
+      // time (DPP row_shr / row_shl) and only xq == 0 / xq == 3 fetch the pixels outside the 32-pixel tile row.  (Two
+      // plain neighbour loads got merged by hipcc with the 16-byte load into a misaligned pair whose registers were
+      // re-sorted right behind the loads: s_waitcnt vmcnt(4); v_mov ... -- a wait for the whole memory latency in
+      // front of every MFMA phase.)
+      r.xl[i] = *reinterpret_cast<const unsigned*>(xq == 0 ? row - 2 : (xq == 3 ? row + 8 : row + 2 * xq));
     }
   };
-  auto store = [&]() {
+  auto store = [&](const Stage& r) {
 #pragma unroll
     for (int i = 0; i < S::NGS_; ++i) {
       const int g = tid + i * NTHREADS;
       if (g >= S::NG) break;
       const int seg = g >> 2, q = g & 3;
-      u32x4 v = gv[i];
+      u32x4 v = r.gv[i];
       if (o0 + (seg >> 2) >= p.cout) v = u32x4{0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4*>(Gs + (seg >> 2) * G_ROW_B + ((seg & 3) * TW + q * 8) * 2) = v;
     }
@@ -744,15 +757,19 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
       const int it = tid + i * NTHREADS;
       if (it >= S::NX) break;
       const int xq = it & 3, xr = (it >> 2) % HRB, xc = it / (4 * HRB);
-      u32x4 mid = xv[i];
-      unsigned l = xl[i], r = xr2[i];
-      if (c0 + xc >= p.cin) { mid = u32x4{0u, 0u, 0u, 0u}; l = 0u; r = 0u; }
+      u32x4 mid = r.xv[i];
+      // lane - 1 / lane + 1 of the same 16-lane row: the neighbouring 8-pixel group (it = tid + i * 768, so xq is the
+      // lane's low two bits); executed by all lanes before any of them leaves the loop
+      const unsigned from_left = __builtin_amdgcn_update_dpp(0u, mid[3], 0x111, 0xF, 0xF, false);
+      const unsigned from_right = __builtin_amdgcn_update_dpp(0u, mid[0], 0x101, 0xF, 0xF, false);
+      unsigned l = xq == 0 ? r.xl[i] : from_left, rt = xq == 3 ? r.xl[i] : from_right;
+      if (c0 + xc >= p.cin) { mid = u32x4{0u, 0u, 0u, 0u}; l = 0u; rt = 0u; }
       // dword k of `mid` holds pixels 2k (low half) and 2k + 1; one pixel to the left / right by v_alignbit
       const unsigned s01 = __builtin_amdgcn_alignbit(mid[1], mid[0], 16);
       const unsigned s12 = __builtin_amdgcn_alignbit(mid[2], mid[1], 16);
       const unsigned s23 = __builtin_amdgcn_alignbit(mid[3], mid[2], 16);
       const u32x4 left = {__builtin_amdgcn_alignbit(mid[0], l, 16), s01, s12, s23};
-      const u32x4 right = {s01, s12, s23, __builtin_amdgcn_alignbit(r, mid[3], 16)};
+      const u32x4 right = {s01, s12, s23, __builtin_amdgcn_alignbit(rt, mid[3], 16)};
       unsigned char* dst = Xs + xc * X_CH_B + xr * X_ROW_B + xq * 16;
       *reinterpret_cast<u32x4*>(dst) = left;                       // kx = 0: pixels x - 1 ..
       *reinterpret_cast<u32x4*>(dst + S::XCOPY) = mid;             // kx = 1
@@ -760,12 +777,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
     }
   };
 
-  if (t_begin < t_end) load(t_begin);
-  for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();   // previous tile's MFMA phase is done with LDS
-    store();
-    __syncthreads();
-    if (t + 1 < t_end) load(t + 1);   // in flight during the MFMA phase
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int s = 0; s < TPB / 16; ++s) {
       const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(aPtr + s * 32));
@@ -776,7 +788,24 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
         acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[jt], 0, 0, 0);
       }
     }
+  };
+  if (t_begin < t_end) load(st0, t_begin);
+  if (t_begin + 1 < t_end) load(st1, t_begin + 1);
+  for (int t = t_begin; t < t_end; t += 2) {
+    ST_LDS_BARRIER();   // previous tile's MFMA phase is done with LDS
+    if (!(p.ablate & 4)) store(st0);
+    ST_LDS_BARRIER();
+    if (t + 2 < t_end) load(st0, t + 2);   // in flight during two MFMA phases
+    if (!(p.ablate & 1)) mfma_tile();
+    if (t + 1 < t_end) {
+      ST_LDS_BARRIER();
+      if (!(p.ablate & 4)) store(st1);
+      ST_LDS_BARRIER();
+      if (t + 3 < t_end) load(st1, t + 3);
+      if (!(p.ablate & 1)) mfma_tile();
+    }
   }
+#undef ST_LDS_BARRIER
 
   float* slab = p.slabs + size_t(split) * p.cout * p.cin * 9;
 #pragma unroll
@@ -1105,6 +1134,7 @@ extern "C" int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g1
   p.gx = (int)grid.x; p.gy = (int)grid.y;
   const dim3 sgrid(grid.x * grid.y * unsigned((pl.nsplit + 7) / 8 * 8));
   if (getenv("ST_WGRAD_NO_XCD")) { p.gx = p.gy = 0; }
+  { const char* e = getenv("ST_WGRAD_ABLATE"); p.ablate = e ? atoi(e) : 0; }
   if (sbo == 64)
     ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), p.gx ? sgrid : grid, dim3(NTHREADS),
                       (bf::SShape<64, 64>::LDS), s, p);
