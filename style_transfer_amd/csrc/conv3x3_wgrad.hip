@@ -68,7 +68,6 @@ struct WgradParams {
   // dy tile sit on gx different XCDs and every L2 fetches it again; here all gx * gy blocks of one pixel range share
   // an XCD, so dy and x leave HBM once.
   int gx = 0, gy = 0;          // 0: plain 3-D grid
-  int ablate = 0;              // TEMP
 };
 
 // BO_ output channels x CI_ input channels per block; BO_ / 32 channel tiles x (CI_ * 9 / 32) column tiles are
@@ -793,16 +792,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
   if (t_begin + 1 < t_end) load(st1, t_begin + 1);
   for (int t = t_begin; t < t_end; t += 2) {
     ST_LDS_BARRIER();   // previous tile's MFMA phase is done with LDS
-    if (!(p.ablate & 4)) store(st0);
+    store(st0);
     ST_LDS_BARRIER();
     if (t + 2 < t_end) load(st0, t + 2);   // in flight during two MFMA phases
-    if (!(p.ablate & 1)) mfma_tile();
+    mfma_tile();
     if (t + 1 < t_end) {
       ST_LDS_BARRIER();
-      if (!(p.ablate & 4)) store(st1);
+      store(st1);
       ST_LDS_BARRIER();
       if (t + 3 < t_end) load(st1, t + 3);
-      if (!(p.ablate & 1)) mfma_tile();
+      mfma_tile();
     }
   }
 #undef ST_LDS_BARRIER
@@ -1134,7 +1133,6 @@ extern "C" int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g1
   p.gx = (int)grid.x; p.gy = (int)grid.y;
   const dim3 sgrid(grid.x * grid.y * unsigned((pl.nsplit + 7) / 8 * 8));
   if (getenv("ST_WGRAD_NO_XCD")) { p.gx = p.gy = 0; }
-  { const char* e = getenv("ST_WGRAD_ABLATE"); p.ablate = e ? atoi(e) : 0; }
   if (sbo == 64)
     ST_LAUNCH_DYN_LDS("st_conv3x3_wgrad_bf16_pre", (bf::conv3x3_wgrad_bf16s_kernel<64, 64>), p.gx ? sgrid : grid, dim3(NTHREADS),
                       (bf::SShape<64, 64>::LDS), s, p);
