@@ -96,7 +96,7 @@ class conv_compute:
 
 
 def _round_bf16(t: torch.Tensor) -> torch.Tensor:
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(torch.bfloat16).to(t.dtype)      # dtype-preserving: the float64 arbiter runs of the tests keep float64
 
 
 class _ConvBf16Operands(torch.autograd.Function):

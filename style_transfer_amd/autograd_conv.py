@@ -179,6 +179,8 @@ class DecoderChainG8Function(torch.autograd.Function):
                                        y_g8=i < n_l - (1 if DecoderChainG8Function.TOP_G8 else 2)))
         ctx.cache, ctx.specs = cache, specs
         ctx.save_for_backward(*acts[:-1], *params)
+        if DecoderChainFunction.TAP is not None:            # test hook: every layer output, as fp32 NCHW
+            DecoderChainFunction.TAP.extend(ops.from_g8(a) if ops.is_g8(a) else a.detach() for a in acts[1:])
         return acts[-1]
 
     @staticmethod

@@ -507,6 +507,17 @@ __global__ __launch_bounds__(256) void wgrad_cout_small_kernel(
         g[o][q] = ok ? v : 0.f;
       }
     }
+    // the bias gradient sums the gradient as it is; the weight gradient of the bf16 mode multiplies bf16 operands
+    // (XG8 = that mode's entry point): dy is rounded to nearest-even here, x already is bf16
+#pragma unroll
+    for (int o = 0; o < CO; ++o) bacc[o] += (g[o][0] + g[o][1]) + (g[o][2] + g[o][3]);
+    if constexpr (XG8) {
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[o][q] = float((__bf16)g[o][q]);
+      }
+    }
     __syncthreads();                                  // previous tile's reads are done
 #pragma unroll
     for (int c = 0; c < WC; ++c)
@@ -515,8 +526,6 @@ __global__ __launch_bounds__(256) void wgrad_cout_small_kernel(
         if (BHR * BHC % 256 == 0 || tid + i * 256 < BHR * BHC)
           xs[c * (BHR * BLD) + loff[i]] = __uint_as_float(__float_as_uint(st_[c][i]) & smask[i]);
     __syncthreads();
-#pragma unroll
-    for (int o = 0; o < CO; ++o) bacc[o] += (g[o][0] + g[o][1]) + (g[o][2] + g[o][3]);
 #pragma unroll
     for (int c = 0; c < WC; ++c) {
       float v[3][6];

@@ -36,8 +36,9 @@ def _run(dec, x0, gy, chain):
 @pytest.mark.parametrize("n,cin,h,w,up,pad", [(2, 64, 32, 64, False, "replicate"), (1, 64, 19, 37, False, "replicate"),
                                                (2, 16, 8, 24, True, "replicate"), (1, 8, 5, 5, False, "zero")])
 def test_top_layer_weight_gradient_from_a_g8_input(n, cin, h, w, up, pad):
-    """st_conv3x3_wgrad_cout3_xg8 reads the G8 activation; the fp32 entry point on the same (bf16) values does the
-    same fp32 arithmetic in the same order: bit-identical."""
+    """st_conv3x3_wgrad_cout3_xg8 reads the G8 activation and rounds dy to bf16 for the weight gradient (the bf16
+    mode multiplies bf16 operands; oracle.ref_ops._ConvBf16Operands.backward) while the bias gradient sums dy as it
+    is; the fp32 entry point on the same values does the same fp32 arithmetic in the same order: bit-identical."""
     from style_transfer_amd import ops
     g = torch.Generator().manual_seed(n + cin + h)
     x = torch.randn(n, cin, h, w, generator=g).cuda()
@@ -45,7 +46,10 @@ def test_top_layer_weight_gradient_from_a_g8_input(n, cin, h, w, up, pad):
     dy = torch.randn(n, 3, h * s, w * s, generator=g).cuda()
     xg = ops.to_g8(x)
     dw, db = ops.conv3x3_wgrad_cout3_g8(xg, dy, upsample2x=up, pad_mode=pad)
-    dw0, db0 = ops.conv3x3_wgrad(ops.from_g8(xg), dy, None, want_bias=True, upsample2x=up, pad_mode=pad, compute="bf16")
+    x32 = ops.from_g8(xg)
+    dw0, _ = ops.conv3x3_wgrad(x32, dy.to(torch.bfloat16).float(), None, want_bias=True, upsample2x=up, pad_mode=pad,
+                               compute="bf16")
+    _, db0 = ops.conv3x3_wgrad(x32, dy, None, want_bias=True, upsample2x=up, pad_mode=pad, compute="bf16")
     assert float(dw0.abs().max()) > 0
     assert torch.equal(dw, dw0) and torch.equal(db, db0)
 
