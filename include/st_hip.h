@@ -183,6 +183,13 @@ size_t st_conv3x3_wgrad_bf16_pre_workspace_bytes(int n, int cout, int cin, int h
 int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g16, const float* bias_slabs, int n_bias_slabs,
                               float* dw, float* dbias, float* workspace, int n, int cin, int hin, int win, int cout,
                               int upsample2x, int pad_mode, st_stream_t stream);
+/* Batched square fp32 products on the fp32 matrix pipe: c[b] = alpha * op(a[b]) . op(b[b]) + diag * I, n x n
+ * row-major matrices, n % 64 == 0, op = transpose where trans_a / trans_b.  The C x C products of
+ * VincentStyleLoss.l2wass_dist (losses.py:67-81: V sqrt(L) V^T, root_cov_stl @ cov_synth @ root_cov_stl and their
+ * gradients, V diag(g) V^T behind eigvalsh) and of the Newton-Schulz square root that stands in for eigh(cov_stl);
+ * replaces torch.matmul / torch.bmm / torch.baddbmm (rocBLAS) there.  c may not alias a or b. */
+int st_bmm_f32(const float* a, const float* b, float* c, int batch, int n, int trans_a, int trans_b, float alpha,
+               float diag, st_stream_t stream);
 /* Weight / bias gradient of the decoder's 3-output-channel top layer (generator.py:127-128; loss.backward() of
  * trainer.py:472) when its input arrives in G8 [n][cin/8][hin][win][8] from the bf16 chain: st_conv3x3_wgrad's
  * vector-ALU form for cout == 3 (fp32 dy [n][3][H][W], fp32 accumulation, fixed-order slab sums) reading the bf16

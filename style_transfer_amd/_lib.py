@@ -43,6 +43,7 @@ SIGNATURES = {
     "st_conv3x3_wgrad_bf16_pre_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "st_conv3x3_wgrad_bf16_pre": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_bmm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "st_conv3x3_wgrad_cout3_xg8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p]),
     "st_grad_join_g8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

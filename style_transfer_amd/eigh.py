@@ -20,6 +20,8 @@ import ctypes
 from ctypes import c_int, c_longlong, c_void_p
 from typing import Dict, List, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -134,6 +136,9 @@ def check() -> None:
                               "intermediate tridiagonal form did not converge to zero)")
 
 
+HIP_BMM = os.environ.get("ST_NO_HIP_BMM") is None      # V diag(g) V^T on st_bmm_f32 (csrc/bmm.hip)
+
+
 class _EigvalshFunction(torch.autograd.Function):
     """torch.linalg.eigvalsh with its backward (d lambda_i / dA = v_i v_i^T): gA = V diag(g) V^T."""
 
@@ -146,7 +151,11 @@ class _EigvalshFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (v,) = ctx.saved_tensors
-        return (v * g.unsqueeze(-2)) @ v.transpose(-1, -2)
+        scaled = v * g.unsqueeze(-2)
+        from . import ops
+        if HIP_BMM and ops.bmm_ok(scaled):
+            return ops.bmm_raw(scaled, v, False, True)
+        return scaled @ v.transpose(-1, -2)
 
 
 def eigvalsh(a: torch.Tensor) -> torch.Tensor:

@@ -369,8 +369,8 @@ class _MomentsFunction(torch.autograd.Function):
 class VincentStyleLoss(nn.Module):
     """losses.py:42-90.  The covariance (the O(C^2 HW) "Gram" term) and its gradient are MFMA kernels
     (csrc/cov.hip); the C x C eigendecompositions of ``l2wass_dist`` are rocSOLVER's syevd -- the driver
-    ``torch.linalg.eigh`` uses -- called directly (``eigh.syevd``: no per-call host read of ``info``), the C x C
-    products stay on ``torch.matmul`` (rocBLAS), as SURVEY.md K7b records.
+    ``torch.linalg.eigh`` uses -- called directly (``eigh.syevd``: no per-call host read of ``info``); the C x C
+    products (round 3) are st_bmm_f32, a hand-written fp32 MFMA batched GEMM (csrc/bmm.hip).
 
     ``forward(input, target)`` is the reference's per-layer call.  A training step has five style layers and the
     decompositions are latency-bound (11.5 ms for [8, 512, 512], 13.0 ms for [16, 512, 512]), so the step engine
@@ -420,6 +420,8 @@ class VincentStyleLoss(nn.Module):
     #: ST_STYLE_ROOT=eigh|newton-schulz overrides the default for A/B runs.
     STYLE_ROOT = os.environ.get("ST_STYLE_ROOT", "newton-schulz")
     NS_ITERS = 16
+    #: the C x C products on st_bmm_f32 (csrc/bmm.hip, fp32 MFMA); ST_NO_HIP_BMM=1: torch.matmul / bmm (rocBLAS), for A/B
+    HIP_BMM = os.environ.get("ST_NO_HIP_BMM") is None
 
     @classmethod
     def _style_side(cls, cov_stl, n_pixels=None):
@@ -428,7 +430,11 @@ class VincentStyleLoss(nn.Module):
             from . import eigh
             eigvals, eigvects = eigh.syevd(cov_stl)
             pos = eigvals.clip(0)
-            root_cov_stl = torch.matmul(eigvects * torch.sqrt(pos).unsqueeze(-2), torch.transpose(eigvects, -1, -2))
+            scaled = eigvects * torch.sqrt(pos).unsqueeze(-2)
+            if ops.bmm_ok(scaled) and cls.HIP_BMM:
+                root_cov_stl = ops.bmm_raw(scaled, eigvects, False, True)
+            else:
+                root_cov_stl = torch.matmul(scaled, torch.transpose(eigvects, -1, -2))
             return root_cov_stl, torch.sum(pos, dim=1, keepdim=True)
         # cov_stl = (x - mu)(x - mu)^T is positive semi-definite: sum(clip(eigenvalues, 0)) is its trace (the argument
         # of _synth_side for tr_cov_synth), and V sqrt(clip(L, 0)) V^T is its principal square root.
@@ -439,9 +445,14 @@ class VincentStyleLoss(nn.Module):
         y = cov_stl / norm                                                          # spectrum in [0, 1]
         z = eye
         eye15 = 1.5 * eye
+        hip = ops.bmm_ok(y) and cls.HIP_BMM
         for _ in range(cls.NS_ITERS):                     # Y -> A^(1/2), Z -> A^(-1/2)
-            t = torch.baddbmm(eye15, z, y, beta=1.0, alpha=-0.5)
-            y, z = torch.bmm(y, t), torch.bmm(t, z)
+            if hip:                                       # T = 1.5 I - 0.5 Z Y in the GEMM's epilogue
+                t = ops.bmm_raw(z.contiguous(), y, alpha=-0.5, diag=1.5)
+                y, z = ops.bmm_raw(y, t), ops.bmm_raw(t, z.contiguous())
+            else:
+                t = torch.baddbmm(eye15, z, y, beta=1.0, alpha=-0.5)
+                y, z = torch.bmm(y, t), torch.bmm(t, z)
         return y * torch.sqrt(norm), tr_cov_stl
 
     @staticmethod
@@ -454,7 +465,10 @@ class VincentStyleLoss(nn.Module):
         # on x - mu exactly like the identity.  Taking the trace saves one of the three batched
         # eigendecompositions per layer.
         tr_cov_synth = torch.diagonal(cov_synth, dim1=-2, dim2=-1).sum(dim=1, keepdim=True)
-        cov_prod = torch.matmul(torch.matmul(root_cov_stl, cov_synth), root_cov_stl)
+        if ops.bmm_ok(cov_synth) and VincentStyleLoss.HIP_BMM and root_cov_stl.shape == cov_synth.shape:
+            cov_prod = ops.bmm(ops.bmm(root_cov_stl, cov_synth), root_cov_stl)
+        else:
+            cov_prod = torch.matmul(torch.matmul(root_cov_stl, cov_synth), root_cov_stl)
         var_overlap = torch.sum(torch.sqrt(eigh.eigvalsh(cov_prod).clip(0.1)), dim=1, keepdim=True)
         return tr_cov_stl + tr_cov_synth - 2 * var_overlap
 

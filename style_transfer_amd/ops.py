@@ -640,3 +640,49 @@ def mean_std(x: torch.Tensor, eps: float = 1e-5) -> Tuple[torch.Tensor, torch.Te
     _lib.check(lib.st_meanstd_fwd(_lib.dev_ptr(x, "x"), _lib.dev_ptr(mean, "mean"), _lib.dev_ptr(std, "std"),
                                   n * c, h * w, float(eps), _lib.stream_ptr()), "st_meanstd_fwd")
     return mean, std
+
+
+# ---- batched C x C products (csrc/bmm.hip) --------------------------------------------------------------------
+def bmm_ok(a: torch.Tensor) -> bool:
+    """Shapes st_bmm_f32 takes: [batch, n, n] fp32 on the GPU with n % 64 == 0 (every VGG19 channel count)."""
+    return a.dim() == 3 and a.shape[-1] == a.shape[-2] and int(a.shape[-1]) % 64 == 0 and a.dtype == torch.float32 and a.is_cuda
+
+
+def bmm_raw(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
+            diag: float = 0.0) -> torch.Tensor:
+    """``alpha * op(a) @ op(b) + diag * I`` for [batch, n, n] fp32 tensors (st_bmm_f32, fp32 MFMA); no autograd."""
+    lib = _lib.load()
+    a, b = a.contiguous(), b.contiguous()
+    assert bmm_ok(a) and tuple(a.shape) == tuple(b.shape), f"bmm: {tuple(a.shape)} x {tuple(b.shape)}"
+    c = torch.empty_like(a)
+    _lib.check(lib.st_bmm_f32(_lib.dev_ptr(a, "a"), _lib.dev_ptr(b, "b"), _lib.dev_ptr(c, "c"), int(a.shape[0]),
+                              int(a.shape[1]), int(trans_a), int(trans_b), float(alpha), float(diag), _lib.stream_ptr()),
+               "st_bmm_f32")
+    return c
+
+
+class _BmmFunction(torch.autograd.Function):
+    """c = op(a) @ op(b) with dA, dB by the same kernel (the four transpose combinations of a GEMM's adjoints)."""
+
+    @staticmethod
+    def forward(ctx, a, b, trans_a, trans_b):
+        ctx.save_for_backward(a, b)
+        ctx.ta, ctx.tb = trans_a, trans_b
+        return bmm_raw(a, b, trans_a, trans_b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ta, tb = ctx.ta, ctx.tb
+        g = g.contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:       # d op(a) = g @ op(b)^T; a stored transposed: d a = (g @ op(b)^T)^T = op(b) @ g^T
+            ga = bmm_raw(b, g, tb, True) if ta else bmm_raw(g, b, False, not tb)
+        if ctx.needs_input_grad[1]:       # d op(b) = op(a)^T @ g; b stored transposed: d b = g^T @ op(a)
+            gb = bmm_raw(g, a, True, ta) if tb else bmm_raw(a, g, not ta, False)
+        return ga, gb, None, None
+
+
+def bmm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False) -> torch.Tensor:
+    """``op(a) @ op(b)`` for [batch, n, n] fp32 tensors, differentiable (st_bmm_f32 forward and backward)."""
+    return _BmmFunction.apply(a.contiguous(), b.contiguous(), bool(trans_a), bool(trans_b))
