@@ -89,6 +89,8 @@ struct ConvParams {
 };
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // lane exchanges / reductions on the DPP path (no LDS traffic)
 __device__ __forceinline__ float dpp_xor1(float v) {      // quad_perm [1, 0, 3, 2]
@@ -788,6 +790,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
         bv[r] = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
       }
+      const short relu_floor = p.relu ? short(0) : short(-32768);      // max with -32768 is the identity
+      const s16x4 relu_floor4 = {relu_floor, relu_floor, relu_floor, relu_floor};
       // one output row (POOL_ = false) or one pooled row from the row pair (nt_, nt_ + 1) (POOL_ = true; fused
       // MaxPool2d((2,2),(2,2),ceil_mode=True): rounding is monotonic, so max-then-round equals the pool of the
       // rounded activation; even lanes hold the 16 pooled pixels)
@@ -797,6 +801,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     const int slot = (POOL_) ? (li >> 1) : li;                                                        \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
       bf16x4 h, l;                                                                                    \
+      if constexpr (!(POOL_) && !SPLIT) {                                                             \
+        /* packed form: two-wide bias add, one conversion per pair, and the ReLU AFTER the rounding as a packed */ \
+        /* signed 16-bit max with 0 (a bf16 with its sign bit set is a negative int16; -0 -> +0 like fmaxf;   */ \
+        /* rounding to nearest even is monotonic and keeps 0, so it commutes with the ReLU: same bits) -- the */ \
+        /* epilogue of the wide, shallow layers is bound by its VALU instruction count                        */ \
+        _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2) {                                            \
+          f32x2 v2 = {acc[mt][nt_][q * 4 + 2 * j2], acc[mt][nt_][q * 4 + 2 * j2 + 1]};                \
+          const f32x2 b2 = {bv[q * 4 + 2 * j2], bv[q * 4 + 2 * j2 + 1]};                              \
+          v2 += b2;                                                                                   \
+          h[2 * j2] = (__bf16)v2[0];                                                                  \
+          h[2 * j2 + 1] = (__bf16)v2[1];                                                              \
+        }                                                                                             \
+        s16x4 hi_ = __builtin_bit_cast(s16x4, h);                                                     \
+        hi_ = __builtin_elementwise_max(hi_, relu_floor4);                                            \
+        h = __builtin_bit_cast(bf16x4, hi_);                                                          \
+      } else                                                                                          \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
         float v = acc[mt][nt_][q * 4 + j];                                                            \
         if (POOL_) {                                                                                  \
