@@ -773,9 +773,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     // stores 16 B per lane: 32 lanes cover 512 contiguous bytes of one channel group's row.  SPLIT: a second
     // patch / store for the lo image.
     constexpr int NPT = C::NPART;
-    unsigned* patch = reinterpret_cast<unsigned*>(smem16 + (PERSIST ? 2 * C::W_UNITS + 2 * C::X_UNITS : 0) +
-                                                  wave * (128 * NPT));
-    const u32x4* patch16 = reinterpret_cast<const u32x4*>(patch);
+    // plain bf16: TWO patches per wave, used by alternate rows -- row r + 1 is packed and written while row r's patch
+    // reads are still in flight (with one patch and a fence after every row the epilogue ran write -> wait -> read ->
+    // wait -> store per row: 1600 cycles per row and wave, 30 % of a 64-channel tile's time by in-kernel stamps)
+    constexpr int NPATCH = SPLIT ? 1 : 2;
+    unsigned* patch0 = reinterpret_cast<unsigned*>(smem16 + (PERSIST ? 2 * C::W_UNITS + 2 * C::X_UNITS : 0) +
+                                                   wave * (128 * NPT * NPATCH));
     u32x4* yg = reinterpret_cast<u32x4*>(p.y);
     const int cgroups = p.cout >> 3;
     const bool pool = p.pool != 0;
@@ -799,6 +802,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   {                                                                                                   \
     const int yy = y0 + wp * NT + (nt_);                                                              \
     const int slot = (POOL_) ? (li >> 1) : li;                                                        \
+    unsigned* patch = patch0 + (NPATCH == 2 ? (((nt_) >> ((POOL_) ? 1 : 0)) & 1) * (128 * 4) : 0);    \
+    const u32x4* patch16 = reinterpret_cast<const u32x4*>(patch);                                     \
+    u32x4 gnxt[2] = {gcur[0], gcur[1]};                                                               \
+    if (!(POOL_) && !SPLIT && p.ogate && (nt_) + 1 < NT) ST_G8_GATES(gnxt, (nt_) + 1);                \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
       bf16x4 h, l;                                                                                    \
       if constexpr (!(POOL_) && !SPLIT) {                                                             \
@@ -849,10 +856,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         const size_t o = (size_t(b) * cgroups + cg) * NPT * plane_y + size_t(yy) * Wy + xs;           \
         _Pragma("unroll") for (int part = 0; part < NPT; ++part) {                                    \
           u32x4 v = patch16[part * 128 + li * 4 + q];                                                 \
-          if (ok) {                                                                                   \
-            if (!SPLIT && p.ogate) v = gate_g8(v, p.ogate[o]);                                        \
-            yg[o + part * plane_y] = v;                                                               \
-          }                                                                                           \
+          if (!SPLIT && p.ogate) v = gate_g8(v, gcur[k]);                                             \
+          if (ok) yg[o + part * plane_y] = v;                                                         \
         }                                                                                             \
       }                                                                                               \
     } else {                                                                                          \
@@ -866,8 +871,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         if (ok) yg[o + part * plane_y] = v;                                                           \
       }                                                                                               \
     }                                                                                                 \
-    asm volatile("" ::: "memory");                                                                    \
+    if (NPATCH == 1) asm volatile("" ::: "memory");                                                   \
+    gcur[0] = gnxt[0];                                                                                \
+    gcur[1] = gnxt[1];                                                                                \
   }
+      // the output gate of row nt_ (st_conv3x3_dgrad_bf16_g8), in the layout of the stores: requested one row AHEAD
+      // and UNCONDITIONALLY on clamped coordinates (a load inside the `ok` branch put a full memory latency in front
+      // of every store: 20 000 of a gated tile's 32 000 epilogue cycles)
+#define ST_G8_GATES(dst_, nt_)                                                                        \
+  {                                                                                                   \
+    const int gy_ = min(y0 + wp * NT + (nt_), p.Ho - 1), gx_ = min(x0 + li, p.Wo - 1);                \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                   \
+      const int cg_ = min((cbase >> 3) + k * 2 + lh, cgroups - 1);                                    \
+      dst_[k] = p.ogate[(size_t(b) * cgroups + cg_) * plane_y + size_t(gy_) * Wy + gx_];              \
+    }                                                                                                 \
+  }
+      u32x4 gcur[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+      if (!SPLIT && !pool && p.ogate) ST_G8_GATES(gcur, 0);
       if (!pool) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) ST_G8_ROW(false, nt)
@@ -876,6 +896,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
         for (int nt = 0; nt + 1 < NT; nt += 2) ST_G8_ROW(true, nt)
       }
 #undef ST_G8_ROW
+#undef ST_G8_GATES
     }
   } else if (p.pool) {
     // fused MaxPool2d((2,2),(2,2),ceil_mode=True) (generator.py:53,60,73), as in csrc/conv3x3.hip
@@ -1060,7 +1081,7 @@ int launch_conv_g8(ConvParams& p, bool xg, bool yg, hipStream_t stream) {
     dim3 pgrid((unsigned)std::min<long long>(p.ntiles, persist ? 256 : p.ntiles));
     ST_LAUNCH_DYN_LDS("st_conv3x3_fwd_bf16_g8",
                       (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), pgrid,
-                      dim3(NTHREADS), C::LDS_BYTES + 8 * 128 * 16, stream, p);
+                      dim3(NTHREADS), C::LDS_BYTES + 2 * 8 * 128 * 16, stream, p);
   } else if (xg && yg)
     ST_LAUNCH_DYN_LDS("st_conv3x3_fwd_bf16_g8",
                       (conv3x3_bf16_kernel<MT, NT, WM, WP, false, false, SPLIT, false, true, true>), grid,
