@@ -741,6 +741,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
       r.xl[i] = *reinterpret_cast<const unsigned*>(xq == 0 ? row - 2 : (xq == 3 ? row + 8 : row + 2 * xq));
     }
   };
+  static_assert(S::NX % NTHREADS == 0, "the DPP neighbour exchange in store() needs whole waves of x items");
   auto store = [&](const Stage& r) {
 #pragma unroll
     for (int i = 0; i < S::NGS_; ++i) {
