@@ -12,9 +12,9 @@
 //     operand fragment is one ds_read_b32 with 32 consecutive floats per half-wave (conflict-free; the +4 keeps the
 //     16-byte vector stores of the straight copy aligned and moves the two k rows a wave reads to different banks).
 //     An operand whose contiguous dimension is k (A not transposed, B transposed) is transposed on the way in: a
-//     thread loads 8 consecutive k of one row (two 16-byte loads) and writes 8 scalars; the other form is a straight
+//     thread loads groups of 4 consecutive k of one row (16-byte loads) and writes scalars; the other form is a straight
 //     copy of 16-byte vectors.
-//   * K chunks of 16, the next chunk's global loads in flight during the current chunk's MFMAs.
+//   * K chunks of 32, the next chunk's global loads in flight during the current chunk's MFMAs.
 #include <cstdint>
 
 #include "common.h"
@@ -24,7 +24,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KC = 16;        // k per chunk
+constexpr int KC = 32;        // k per chunk
 constexpr int NT = 256;       // 4 waves
 
 struct BmmParams {
@@ -40,7 +40,7 @@ struct BmmParams {
 // (element (m, k) at src[m * n + k]); else m is contiguous (element at src[k * n + m]).
 template <int BT>
 struct Stage {
-  static constexpr int NV = BT * KC / 4 / NT;    // 16-byte vectors per thread (2 for BT = 128, 1 for BT = 64)
+  static constexpr int NV = BT * KC / 4 / NT;    // 16-byte vectors per thread (4 for BT = 128, 2 for BT = 64)
   f32x4 v[NV];
 };
 
