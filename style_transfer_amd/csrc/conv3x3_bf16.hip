@@ -886,6 +886,70 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       dst_[k] = p.ogate[(size_t(b) * cgroups + cg_) * plane_y + size_t(gy_) * Wy + gx_];              \
     }                                                                                                 \
   }
+      // Plain bf16, no pool: the rows as a two-stage pipeline.  PACK(r): bias / ReLU / rounding, the row's patch
+      // written, its two 16-byte patch reads ISSUED; STORE(r - 1): the previous row's reads (in flight under PACK(r)'s
+      // ~45 VALU instructions) gated and stored.  In-kernel stamps had every row paying an exposed LDS round trip
+      // (2 x ~250 cycles) between its pack and its stores: 4 000 of the epilogue's 12 800 cycles per tile.
+#define ST_G8_PACK(nt_)                                                                               \
+  {                                                                                                   \
+    unsigned* patch = patch0 + ((nt_) & 1) * (128 * 4);                                               \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+      bf16x4 h;                                                                                       \
+      _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2) {                                              \
+        f32x2 v2 = {acc[mt][nt_][q * 4 + 2 * j2], acc[mt][nt_][q * 4 + 2 * j2 + 1]};                  \
+        const f32x2 b2 = {bv[q * 4 + 2 * j2], bv[q * 4 + 2 * j2 + 1]};                                \
+        v2 += b2;                                                                                     \
+        h[2 * j2] = (__bf16)v2[0];                                                                    \
+        h[2 * j2 + 1] = (__bf16)v2[1];                                                                \
+      }                                                                                               \
+      s16x4 hi_ = __builtin_bit_cast(s16x4, h);                                                       \
+      hi_ = __builtin_elementwise_max(hi_, relu_floor4);                                              \
+      const u32x2 hv = __builtin_bit_cast(u32x2, hi_);                                                \
+      patch[(li * 4 + q) * 4 + lh * 2 + 0] = hv[0];                                                   \
+      patch[(li * 4 + q) * 4 + lh * 2 + 1] = hv[1];                                                   \
+    }                                                                                                 \
+    asm volatile("" ::: "memory");                                                                    \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                     \
+      vq[(nt_) & 1][k] = reinterpret_cast<const u32x4*>(patch)[li * 4 + k * 2 + lh];                  \
+  }
+#define ST_G8_STORE(nt_)                                                                              \
+  {                                                                                                   \
+    const int yy = y0 + wp * NT + (nt_);                                                              \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                   \
+      const int cg = (cbase >> 3) + k * 2 + lh, xs = x0 + li;                                         \
+      const bool ok = cg < cgroups && yy < p.Ho && xs < p.Wo;                                         \
+      const size_t o = (size_t(b) * cgroups + cg) * plane_y + size_t(yy) * Wy + xs;                   \
+      u32x4 v = vq[(nt_) & 1][k];                                                                     \
+      if (p.ogate) v = gate_g8(v, gq[(nt_) & 1][k]);                                                  \
+      if (ok) yg[o] = v;                                                                              \
+    }                                                                                                 \
+  }
+      if constexpr (!SPLIT) {
+        if (!pool) {
+          u32x4 vq[2][2], gq[2][2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) gq[i][k] = u32x4{0u, 0u, 0u, 0u};
+          if (p.ogate) {
+            ST_G8_GATES(gq[0], 0);
+            if (NT > 1) ST_G8_GATES(gq[1], 1);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            ST_G8_PACK(nt);
+            if (nt > 0) {
+              ST_G8_STORE(nt - 1);
+              if (p.ogate && nt + 1 < NT) ST_G8_GATES(gq[(nt + 1) & 1], nt + 1);
+            }
+          }
+          ST_G8_STORE(NT - 1);
+          asm volatile("" ::: "memory");     // the next channel tile's PACK(0) writes patch 0 again
+          continue;
+        }
+      }
+#undef ST_G8_PACK
+#undef ST_G8_STORE
       u32x4 gcur[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
       if (!SPLIT && !pool && p.ogate) ST_G8_GATES(gcur, 0);
       if (!pool) {
