@@ -485,6 +485,51 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   }
   // One chunk of an XG kernel: both operands of chunk c+1 arrive by LDS-DMA while the 9 taps of chunk c run with
   // the operand reads of tap t+1 issued before the MFMAs of tap t.
+  //
+  // Plain bf16 (ROWS): the pixel operand of tap (dy, dx) and row nt is halo row nt + dy at column shift dx -- the taps
+  // of one dx re-read the same NT + 2 halo rows three times.  They are read ONCE per chunk instead, into a register
+  // window pbr[dx][row] (taps of dy = 0 read rows 0 .. NT-1 of their dx, taps of dy > 0 only the new row NT-1 + dy):
+  // 18 instead of 36 pixel-operand reads per chunk, a third of the LDS read traffic of the loop (the LDS pipe was
+  // ~75 % busy under the MFMAs and the leading wave of a SIMD still waited on it).  Same operands in the same MFMA
+  // order: bit-identical.
+#define ST_READ_TAP_R(chunk_, tap_, s_)                                                    \
+  {                                                                                        \
+    const u32x4* aP = aPtr + ((chunk_) & 1) * C::W_UNITS;                                  \
+    const u32x4* bP = bPtr + ((chunk_) & 1) * C::X_UNITS;                                  \
+    const int dy = (tap_) / 3, dx = (tap_) % 3;                                            \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+        pa[s_][mt] = __builtin_bit_cast(bf16x8, aP[(tap_) * 2 * C::BM + mt * 32]);         \
+    if (dy == 0) {                                                                         \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+          pbr[dx][nt] = __builtin_bit_cast(bf16x8, bP[nt * HC + dx]);                      \
+    } else {                                                                               \
+      pbr[dx][NT - 1 + dy] = __builtin_bit_cast(bf16x8, bP[(NT - 1 + dy) * HC + dx]);      \
+    }                                                                                      \
+  }
+#define ST_MFMA_TAP_R(tap_, s_)                                                            \
+  {                                                                                        \
+    const int dy = (tap_) / 3, dx = (tap_) % 3;                                            \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s_][mt], pbr[dx][nt + dy], \
+                                                              acc[mt][nt], 0, 0, 0);       \
+  }
+#define ST_CHUNK_DMA_R(chunk_, MORE1_)                                                     \
+  {                                                                                        \
+    ST_READ_TAP_R(chunk_, 0, 0);                                                           \
+    if (MORE1_) {                                                                          \
+      if (!(p.ablate & 4)) ST_ISSUE_W((chunk_) + 1);                                       \
+      if (!(p.ablate & 2)) ST_ISSUE_XG((chunk_) + 1);                                      \
+    }                                                                                      \
+    asm volatile("" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                        \
+      if (t < 8) ST_READ_TAP_R(chunk_, t + 1, (t + 1) & 1);                                \
+      ST_MFMA_TAP_R(t, t & 1);                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+    }                                                                                      \
+    if (MORE1_) { ST_BARRIER_DRAIN_XG(((chunk_) + 1) & 1); } else { ST_BARRIER_DRAIN(); }  \
+  }
 #define ST_CHUNK_DMA(chunk_, MORE1_)                                                       \
   {                                                                                        \
     ST_READ_TAP(chunk_, 0, 0);                                                             \
@@ -556,10 +601,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
   }
   if constexpr (XG) { ST_BARRIER_DRAIN_XG(0); } else { ST_BARRIER_DRAIN(); }
   if constexpr (XG) {
-    bf16x8 pa[2][MT], pb[2][NT], pal[SPLIT ? 2 : 1][MT], pbl[SPLIT ? 2 : 1][NT];
-    int chunk = 0;
-    for (; chunk + 1 < nch; ++chunk) ST_CHUNK_DMA(chunk, true);
-    ST_CHUNK_DMA(chunk, false);
+    if constexpr (!SPLIT) {
+      bf16x8 pa[2][MT], pbr[3][NT + 2];
+      int chunk = 0;
+      for (; chunk + 1 < nch; ++chunk) ST_CHUNK_DMA_R(chunk, true);
+      ST_CHUNK_DMA_R(chunk, false);
+    } else {
+      bf16x8 pa[2][MT], pb[2][NT], pal[SPLIT ? 2 : 1][MT], pbl[SPLIT ? 2 : 1][NT];
+      int chunk = 0;
+      for (; chunk + 1 < nch; ++chunk) ST_CHUNK_DMA(chunk, true);
+      ST_CHUNK_DMA(chunk, false);
+    }
   } else if constexpr (PIPE) {
     bf16x8 pa[2][MT], pb[2][NT], pal[SPLIT ? 2 : 1][MT], pbl[SPLIT ? 2 : 1][NT];
     int chunk = 0;
