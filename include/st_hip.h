@@ -293,6 +293,23 @@ int st_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, int ceil_m
  * st_maxpool2x2_fwd followed by the bf16 rounding of that conv's staging. */
 int st_maxpool2x2_fwd_g8(const float* x, void* y_g8, int n, int c, int h, int w, st_stream_t stream);
 
+/* The pool-input layers of a bf16-mode chain UNDER AUTOGRAD (the loss VGG's conv1_2 / conv2_2 / conv3_4 in front of
+ * torchvision's 'M' layers, trainer.py:165-199, on the decoded image -- trainer.py:446-457, backward :472):
+ * conv + ReLU + 2x2 max pool with the pooled activation in G8 [n][cout/8][h/2][w/2][8] and `codes`, one byte per
+ * pooled pixel and channel in the same order ([n][cout/8][h/2][w/2][8] uint8): bits 0-1 = the window position
+ * (0 1 / 2 3) of the maximum under torch.max_pool2d's backward rule (the first maximum in scan order), bit 2 = that
+ * maximum is > 0.  The full-resolution activation is not written.  Even h and w; cout % 8 == 0; x as in
+ * st_conv3x3_fwd_bf16_g8.  The pooled values are the bits st_conv3x3_fwd_bf16_g8(pool = 1) writes. */
+int st_conv3x3_pool_fwd_bf16_g8_codes(const void* x, int x_g8, const void* w_packed, const float* bias,
+                                      void* y_pooled_g8, void* codes, int n, int cin, int hin, int win, int cout,
+                                      int pad_mode, int relu, st_stream_t stream);
+/* ... and its backward half: the G8 gradient w.r.t. the pooled activation [n][c/8][h/2][w/2][8] routed to the
+ * position the code names where the code's bit 2 is set, zeros elsewhere -> G8 [n][c/8][h][w][8], the (already ReLU-
+ * gated) operand of st_conv3x3_dgrad_bf16_g8.  Same values as st_grad_join_g8(chain_pooled, x_gate) on the
+ * full-resolution activation. */
+int st_grad_pool_codes_g8(const void* g_pooled_g8, const void* codes, void* out_g8, int n, int c, int h, int w,
+                          st_stream_t stream);
+
 /* backward: x is the pool INPUT [nc][h][w], dy [nc][ho][wo]; dx [nc][h][w] fully overwritten.
  * Ties go to the first maximum in scan order, as torch.max_pool2d does. */
 int st_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,

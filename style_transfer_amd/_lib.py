@@ -82,6 +82,9 @@ SIGNATURES = {
     "st_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
     "st_conv1x1_3to3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "st_maxpool2x2_fwd_g8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_pool_fwd_bf16_g8_codes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_grad_pool_codes_g8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_adain_fwd_dev_eps": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float,
                                      c_void_p, c_void_p]),

@@ -18,6 +18,7 @@ round trips: no separate pool-backward, accumulate or ReLU-backward kernels, hal
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Sequence, Tuple
 
 import torch
@@ -34,6 +35,9 @@ from . import ops
 # gradient, the NaN makes that visible at once instead of silently dropping a term.
 _AFFINE: Dict[int, torch.Tensor] = {}
 AFFINE_TAPS = True          # ST_NO_AFFINE_TAPS=1 (read in loss_network) keeps the tensor hand-over
+# pool-input layers nobody captures: conv + ReLU + pool in one launch, winner codes for the backward
+# (ops.conv3x3_pool_g8_codes); ST_NO_POOL_CODES=1 keeps the fp32 activation + maxpool2x2_g8 + pooled join (A/B, tests)
+POOL_CODES = os.environ.get("ST_NO_POOL_CODES") is None
 
 
 def lazy_affine_grad(tap: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
@@ -101,9 +105,14 @@ class VGGChainFunction(torch.autograd.Function):
         saved: List[torch.Tensor] = []
         meta = []                       # per unit: dict(kind, idx, ..., slot of the saved tensor)
         cur = x.contiguous()
+        fused_pool = False              # the conv unit before this pool unit already pooled (winner codes saved)
         for k, u in enumerate(units):
             if u[0] == "pool":
                 idx = u[1]
+                if fused_pool:
+                    fused_pool = False
+                    meta.append({"kind": "pool", "idx": idx, "fused": True})
+                    continue
                 c, h, w = int(cur.shape[1]), int(cur.shape[2]), int(cur.shape[3])
                 if idx not in post and k + 1 < len(units) and h % 2 == 0 and w % 2 == 0 and c % 16 == 0:
                     cur = ops.maxpool2x2_g8(cur)         # nobody captures it: straight into the next conv's input form
@@ -133,6 +142,15 @@ class VGGChainFunction(torch.autograd.Function):
                 assert cont, "a conv that ends the network is captured before its ReLU"
                 captured = idx in post or idx + 1 in post
                 y_g8 = not captured and not pool_next and has_next and cout % 8 == 0
+                hh, ww = int(cur.shape[2]), int(cur.shape[3])
+                if (POOL_CODES and pool_next and not captured and units[k + 1][1] not in post and k + 2 < len(units)
+                        and cout % 16 == 0 and hh % 2 == 0 and ww % 2 == 0 and (ops.is_g8(cur) or cin % 16 == 0)):
+                    cur, codes = ops.conv3x3_pool_g8_codes(cur, wp, bias, cout, ops.PAD_ZERO, relu=True)
+                    m["codes"], m["shape"], m["slot"] = True, (int(x.shape[0]), cout, hh, ww), len(saved)
+                    saved.append(codes)
+                    meta.append(m)
+                    fused_pool = True
+                    continue
                 y = ops.conv3x3_g8(cur, wp, bias, cout, False, ops.PAD_ZERO, relu=True, pool=False, y_g8=y_g8)
                 m["g8"] = y_g8
                 if captured:
@@ -161,6 +179,10 @@ class VGGChainFunction(torch.autograd.Function):
         for k in range(len(meta) - 1, -1, -1):
             m = meta[k]
             if m["kind"] == "pool":
+                if m.get("fused"):
+                    assert kind in (None, "g8")         # the launch above wrote the pooled gradient in G8, ungated
+                    kind = "pooled_g8" if g is not None else None
+                    continue
                 assert kind in (None, "f32")
                 tap = grads.get(("post", m["idx"]))
                 assert affs.get(("post", m["idx"])) is None, "pool outputs are never marked for the affine hand-over"
@@ -172,7 +194,10 @@ class VGGChainFunction(torch.autograd.Function):
                 continue
             idx = m["idx"]
             y = saved[m["slot"]]
-            if m["g8"]:
+            if m.get("codes"):
+                assert kind in (None, "pooled_g8")
+                g_in = ops.grad_pool_codes_g8(g, y) if g is not None else None      # y: the winner codes
+            elif m["g8"]:
                 assert kind in (None, "g8")
                 g_in = g                                        # gated by the launch above
             else:
@@ -206,6 +231,8 @@ class VGGChainFunction(torch.autograd.Function):
             below = meta[k - 1] if k > 0 else None
             if below is None:
                 dx = ops.conv3x3_dgrad_g8(g_in, wpt, m["cin"], dx_g8=False)
+            elif below["kind"] == "pool" and below.get("fused"):
+                kind, g = "g8", ops.conv3x3_dgrad_g8(g_in, wpt, m["cin"], dx_g8=True)       # the codes carry the gate
             elif below["kind"] == "conv" and below["g8"]:
                 kind, g = "g8", ops.conv3x3_dgrad_g8(g_in, wpt, m["cin"], dx_g8=True, dx_gate=saved[below["slot"]])
             else:

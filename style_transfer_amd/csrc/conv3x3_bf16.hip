@@ -65,6 +65,10 @@ struct ConvParams {
   int cout, H, W;          // conv-input spatial dims, after the optional upsample
   int Ho, Wo;              // output dims: (H, W) forward; (H+2, W+2) for the padded data gradient
   int pool;                // 1: the epilogue writes maxpool2x2(ceil_mode) of the activation instead of it
+  // G8 pooled output only (st_conv3x3_pool_fwd_bf16_g8_codes; even Ho, Wo): one byte per pooled pixel and channel,
+  // [n][c/8][Ho/2][Wo/2][8] -- bits 0-1 = the window position (row-major scan order) that holds the maximum under the
+  // max-pool backward's tie rule (the first maximum wins), bit 2 = that maximum is > 0 (the ReLU gate)
+  unsigned* pcodes = nullptr;
   int ldo;                 // output row stride in floats (Wo, or Wo rounded up to 4 in the padded workspace)
   int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
@@ -860,6 +864,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     if (!(POOL_) && !SPLIT && p.ogate && (nt_) + 1 < NT) ST_G8_GATES(gnxt, (nt_) + 1);                \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
       bf16x4 h, l;                                                                                    \
+      unsigned cw = 0;                                                                                \
       if constexpr (!(POOL_) && !SPLIT) {                                                             \
         /* packed form: two-wide bias add, one conversion per pair, and the ReLU AFTER the rounding as a packed */ \
         /* signed 16-bit max with 0 (a bf16 with its sign bit set is a negative int16; -0 -> +0 like fmaxf;   */ \
@@ -878,15 +883,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       } else                                                                                          \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
         float v = acc[mt][nt_][q * 4 + j];                                                            \
+        if ((POOL_) && !SPLIT && p.pcodes) {                                                          \
+          /* window (a an / c cn) of the even lane, biased first: the comparisons see the activation's own values */ \
+          const float a = v + bv[q * 4 + j];                                                          \
+          const float c = acc[mt][(nt_) + 1 < NT ? (nt_) + 1 : (nt_)][q * 4 + j] + bv[q * 4 + j];     \
+          const float an = __shfl_xor(a, 1, 64), cn = __shfl_xor(c, 1, 64);                           \
+          float m = a;                                                                                \
+          unsigned arg = 0;                                                                           \
+          if (an > m || an != an) { m = an; arg = 1; }                                                \
+          if (c > m || c != c) { m = c; arg = 2; }                                                    \
+          if (cn > m || cn != cn) { m = cn; arg = 3; }                                                \
+          cw |= (arg | (m > 0.f ? 4u : 0u)) << (8 * j);                                               \
+          v = m;                                                                                      \
+        } else {                                                                                      \
         if (POOL_) {                                                                                  \
           if (yy + 1 < p.Ho) v = fmaxf(v, acc[mt][(nt_) + 1 < NT ? (nt_) + 1 : (nt_)][q * 4 + j]);    \
           const float vn = __shfl_xor(v, 1, 64);                                                      \
           if (x0 + li + 1 < p.Wo) v = fmaxf(v, vn);                                                   \
         }                                                                                             \
         v += bv[q * 4 + j];                                                                           \
+        }                                                                                             \
         if (p.relu) v = fmaxf(v, 0.f);                                                                \
         h[j] = (__bf16)v;                                                                             \
         if (SPLIT) l[j] = (__bf16)(v - float(h[j]));                                                  \
+      }                                                                                               \
+      if ((POOL_) && !SPLIT && p.pcodes && !(li & 1)) {                                               \
+        const int cg_ = (cbase >> 3) + q;                                                             \
+        if (cg_ < cgroups && yy < p.Ho && x0 + li < p.Wo)                                             \
+          p.pcodes[(((size_t(b) * cgroups + cg_) * Hy + (yy >> 1)) * Wy + ((x0 + li) >> 1)) * 2 + lh] = cw; \
       }                                                                                               \
       if (!(POOL_) || !(li & 1)) {                                                                    \
         const u32x2 hv = __builtin_bit_cast(u32x2, h);                                                \
@@ -1366,7 +1390,7 @@ extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, co
 static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
                                int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
                                int pad_mode, int relu, int pool, st_stream_t stream, bool split,
-                               const void* ogate = nullptr) {
+                               const void* ogate = nullptr, void* pool_codes = nullptr) {
   ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16_g8: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
              "st_conv3x3_fwd_bf16_g8: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
@@ -1386,6 +1410,7 @@ static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, co
   ConvParams p;
   p.x = (const float*)x; p.gate = nullptr; p.wp = (const u32x4*)w_packed; p.bias = bias; p.y = (float*)y;
   p.ogate = (const u32x4*)ogate;
+  p.pcodes = (unsigned*)pool_codes;
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
   p.up = upsample2x ? 1 : 0;
   p.H = hin << p.up; p.W = win << p.up;
@@ -1406,6 +1431,20 @@ extern "C" int st_conv3x3_fwd_bf16_g8(const void* x, int x_g8, const void* w_pac
                                       int pad_mode, int relu, int pool, st_stream_t stream) {
   return conv3x3_fwd_g8_impl(x, x_g8, w_packed, bias, y, y_g8, n, cin, hin, win, cout, upsample2x, pad_mode, relu,
                              pool, stream, false);
+}
+
+// The pool-input layers of a G8 chain under autograd (the loss VGG's conv1_2 / conv2_2 / conv3_4, trainer.py:165-199):
+// conv + ReLU + 2 x 2 max pool with the POOLED activation written in G8 and, for the backward, one byte per pooled
+// pixel and channel (ConvParams::pcodes) -- the full-resolution activation, which the backward only ever used to find
+// the window's winner and its sign, is never written.
+extern "C" int st_conv3x3_pool_fwd_bf16_g8_codes(const void* x, int x_g8, const void* w_packed, const float* bias,
+                                                 void* y_pooled_g8, void* codes, int n, int cin, int hin, int win,
+                                                 int cout, int pad_mode, int relu, st_stream_t stream) {
+  ST_REQUIRE(codes && reinterpret_cast<uintptr_t>(codes) % 8 == 0, "st_conv3x3_pool_fwd_bf16_g8_codes: codes must be 8-byte aligned");
+  ST_REQUIRE(hin > 0 && win > 0 && hin % 2 == 0 && win % 2 == 0,
+             "st_conv3x3_pool_fwd_bf16_g8_codes: even h and w expected (got %dx%d)", hin, win);
+  return conv3x3_fwd_g8_impl(x, x_g8, w_packed, bias, y_pooled_g8, 1, n, cin, hin, win, cout, 0, pad_mode, relu, 1,
+                             stream, false, nullptr, codes);
 }
 
 extern "C" int st_conv3x3_fwd_bf16x3_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,

@@ -23,6 +23,7 @@
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -264,6 +265,52 @@ extern "C" int st_grad_join_g8_affine(const float* chain, const float* chain_poo
                                       int w, st_stream_t stream) {
   return grad_join_impl(chain, chain_pooled, x_gate, add_post, add_pre, aff_x, aff_post, aff_pre, out_g8, n, c, h, w,
                         stream);
+}
+
+// Max-pool backward from the winner codes of st_conv3x3_pool_fwd_bf16_g8_codes: the G8 gradient w.r.t. the pooled
+// activation goes to the window position named by bits 0-1 of the channel's code when bit 2 (maximum > 0) is set; the
+// other three positions are zero.  item = (image, channel group, pooled pixel): 16 + 8 bytes in, 64 bytes out.
+__global__ __launch_bounds__(256) void grad_pool_codes_kernel(const u32x4* __restrict__ g, const u32x2* __restrict__ codes,
+                                                              u32x4* __restrict__ out, int ho, int wo, long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ox = int(e % wo);
+    long long t = e / wo;
+    const int oy = int(t % ho);
+    const long long plane = t / ho;                    // image * groups + group
+    const u32x4 gv = g[e];
+    const u32x2 cv = codes[e];
+    u32x4 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned code = (cv[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      const unsigned lane = gv[j >> 1] & ((j & 1) ? 0xffff0000u : 0x0000ffffu);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (code == (4u | unsigned(k))) o[k][j >> 1] |= lane;
+    }
+    u32x4* dst = out + (plane * (2 * ho) + 2 * oy) * (long long)(2 * wo) + 2 * ox;
+    dst[0] = o[0];
+    dst[1] = o[1];
+    dst[2 * wo] = o[2];
+    dst[2 * wo + 1] = o[3];
+  }
+}
+
+extern "C" int st_grad_pool_codes_g8(const void* g_pooled_g8, const void* codes, void* out_g8, int n, int c, int h,
+                                     int w, st_stream_t stream) {
+  ST_REQUIRE(g_pooled_g8 && codes && out_g8, "st_grad_pool_codes_g8: null pointer");
+  ST_REQUIRE(n > 0 && c > 0 && c % 8 == 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0,
+             "st_grad_pool_codes_g8: bad dims n=%d c=%d h=%d w=%d (c %% 8 == 0, even h and w)", n, c, h, w);
+  ST_REQUIRE(reinterpret_cast<uintptr_t>(g_pooled_g8) % 16 == 0 && reinterpret_cast<uintptr_t>(out_g8) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(codes) % 8 == 0,
+             "st_grad_pool_codes_g8: 16-byte aligned G8 tensors and 8-byte aligned codes expected");
+  const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2);
+  hipLaunchKernelGGL(grad_pool_codes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)g_pooled_g8, (const u32x2*)codes, (u32x4*)out_g8, h / 2, w / 2, total);
+  return st::check_launch("st_grad_pool_codes_g8");
 }
 
 extern "C" int st_maxpool2x2_fwd_g8(const float* x, void* y_g8, int n, int c, int h, int w, st_stream_t stream) {

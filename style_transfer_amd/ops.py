@@ -266,6 +266,50 @@ def conv3x3_g8(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     return y
 
 
+def conv3x3_pool_g8_codes(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+                          pad_mode="zero", relu: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """conv + ReLU + 2x2 max pool of a bf16-mode chain under autograd (st_conv3x3_pool_fwd_bf16_g8_codes): the pooled
+    activation in G8 and the uint8 winner codes [n, cout/8, h/2, w/2, 8] that grad_pool_codes_g8 routes the gradient
+    by.  ``x`` fp32 NCHW or G8; even h and w."""
+    lib = _lib.load()
+    x_g8 = is_g8(x)
+    if x_g8:
+        n, cin, h, w = int(x.shape[0]), int(x.shape[1]) * 8, int(x.shape[2]), int(x.shape[3])
+    else:
+        assert x.dim() == 4 and x.dtype == torch.float32
+        n, cin, h, w = (int(v) for v in x.shape)
+    assert x.is_contiguous() and h % 2 == 0 and w % 2 == 0 and cout % 8 == 0
+    assert conv_family(w_packed, cout, cin) == "bf16", "conv3x3_pool_g8_codes needs bf16-packed weights"
+    y = torch.empty((n, cout // 8, h // 2, w // 2, 8), dtype=torch.bfloat16, device=x.device)
+    codes = torch.empty((n, cout // 8, h // 2, w // 2, 8), dtype=torch.uint8, device=x.device)
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cout, "bf16"), 2.0 * n * h * w * cin * cout * 9,
+                                 float(x.numel() * x.element_size() + y.numel() * 3))
+    _lib.check(lib.st_conv3x3_pool_fwd_bf16_g8_codes(
+        _lib.dev_ptr(x, "x", x.dtype), int(x_g8), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
+        _lib.dev_ptr(bias, "bias") if bias is not None else None, _lib.dev_ptr(y, "y", torch.bfloat16),
+        _lib.dev_ptr(codes, "codes", torch.uint8), n, cin, h, w, cout, _pad_code(pad_mode), int(relu),
+        _lib.stream_ptr()), "st_conv3x3_pool_fwd_bf16_g8_codes")
+    if ev is not None:
+        ev.record()
+    return y, codes
+
+
+def grad_pool_codes_g8(g_pooled: torch.Tensor, codes: torch.Tensor) -> torch.Tensor:
+    """The G8 gradient w.r.t. a pooled activation routed through conv3x3_pool_g8_codes' winner codes
+    (st_grad_pool_codes_g8): G8 [n, c/8, 2h, 2w, 8], ReLU gate included."""
+    lib = _lib.load()
+    assert is_g8(g_pooled) and codes.dtype == torch.uint8 and tuple(codes.shape) == tuple(g_pooled.shape)
+    n, cg, ho, wo = (int(v) for v in g_pooled.shape[:4])
+    out = torch.empty((n, cg, 2 * ho, 2 * wo, 8), dtype=torch.bfloat16, device=g_pooled.device)
+    _lib.check(lib.st_grad_pool_codes_g8(_lib.dev_ptr(g_pooled, "g_pooled", torch.bfloat16),
+                                         _lib.dev_ptr(codes, "codes", torch.uint8),
+                                         _lib.dev_ptr(out, "out", torch.bfloat16), n, cg * 8, 2 * ho, 2 * wo,
+                                         _lib.stream_ptr()), "st_grad_pool_codes_g8")
+    return out
+
+
 def conv3x3_dgrad(dy: torch.Tensor, y_gate: Optional[torch.Tensor], w_packed_t: torch.Tensor, cin: int,
                   upsample2x: bool = False, pad_mode="replicate",
                   dx_gate: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -266,3 +266,76 @@ def test_affine_tap_handover_is_bit_identical_to_the_tensor_form(n, h, w):
     assert float(ref.abs().max()) > 0
     assert torch.equal(got_loss, ref_loss)
     assert torch.equal(got, ref)
+
+
+# ---- pool-input layers nobody captures: conv + ReLU + pool in one launch, winner codes for the backward ---------------
+def _codes_ref(y_full):
+    """(position of the first maximum in scan order, maximum > 0) per 2 x 2 window, in G8 order [n, c/8, h/2, w/2, 8]"""
+    n, c, h, w = y_full.shape
+    win = y_full.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+    top = win.max(-1, keepdim=True).values
+    eq = win == top
+    first = eq & (eq.cumsum(-1) == 1)
+    arg = first.to(torch.uint8).argmax(-1)
+    pos = top[..., 0] > 0
+    g8 = lambda t: t.reshape(n, c // 8, 8, h // 2, w // 2).permute(0, 1, 3, 4, 2).contiguous()   # noqa: E731
+    return g8(arg), g8(pos)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,x_g8", [
+    (2, 64, 64, 32, 64, False),        # conv1_2's form: fp32 tap in, 64-channel tile
+    (1, 64, 128, 48, 40, True),        # partial pixel tiles
+    (2, 256, 256, 16, 32, True),       # conv3_4's form
+    (1, 16, 32, 34, 6, True),          # the 32-channel tile, rows past the tile
+    (1, 128, 48, 20, 36, False),       # a channel tail inside the last 64-channel tile
+])
+def test_conv_pool_codes_forward_and_backward(ops, n, cin, cout, h, w, x_g8):
+    x = torch.relu(_rand((n, cin, h, w), 51))
+    wt = _rand((cout, cin, 3, 3), 52, 0.05)
+    bias = _rand((cout,), 53, 0.1)
+    wp = ops.pack_conv3x3_weights(wt, False, "bf16")
+    xin = ops.to_g8(x) if x_g8 else x
+    y_full = ops.conv3x3_g8(xin, wp, bias, cout, False, ops.PAD_ZERO, relu=True, pool=False, y_g8=False)
+    y_pool, codes = ops.conv3x3_pool_g8_codes(xin, wp, bias, cout, ops.PAD_ZERO, relu=True)
+    assert torch.equal(y_pool, ops.maxpool2x2_g8(y_full))
+    arg, pos = _codes_ref(y_full)
+    assert torch.equal((codes & 4) != 0, pos)
+    assert int((codes > 7).sum()) == 0
+    # the position only matters (and is only defined by the ReLU output) where the maximum is positive
+    assert torch.equal((codes & 3)[pos], arg[pos])
+    g = ops.to_g8(_rand((n, cout, h // 2, w // 2), 54))
+    got = ops.grad_pool_codes_g8(g, codes)
+    ref = ops.grad_join_g8((n, cout, h, w), chain_pooled=ops.from_g8(g), x_gate=y_full)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("sets,n,h,w", [
+    ([[21], [2, 7, 14, 19, 25]], 2, 64, 64),          # the CLI defaults: conv3_4 is the one uncaptured pool input
+    ([[21], [14, 19, 25]], 1, 64, 96),                # conv1_2 and conv2_2 uncaptured as well
+    ([[21], [1, 6, 25]], 1, 72, 88),                  # 9 x 11 at the third pool: that layer keeps the odd-size route
+])
+def test_pool_codes_chain_is_bit_identical_to_the_fp32_pool_input_form(sets, n, h, w):
+    from style_transfer_amd import autograd_vgg, precision
+    net = _extractor(sets)
+    x0 = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(9)).cuda()
+    weights = [torch.randn(1, generator=torch.Generator().manual_seed(60 + k)).item() for k in range(16)]
+
+    def run(codes):
+        autograd_vgg.POOL_CODES = codes
+        x = x0.clone().requires_grad_(True)
+        with precision.compute_dtype("bf16"):
+            outs = net.forward_multi(x, sets)
+            flat = [t for s in outs for t in s]
+            loss = sum(wt * (t * t).mean() + 0.1 * wt * t.mean() for wt, t in zip(weights, flat))
+            loss.backward()
+        return [t.detach() for t in flat], x.grad
+
+    try:
+        ref_out, ref_grad = run(False)
+        got_out, got_grad = run(True)
+    finally:
+        autograd_vgg.POOL_CODES = True
+    for a, b in zip(got_out, ref_out):
+        assert torch.equal(a, b)
+    assert float(ref_grad.abs().max()) > 0
+    assert torch.equal(got_grad, ref_grad)
