@@ -710,35 +710,50 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
   };
   Stage st0, st1;
 #define ST_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  auto load = [&](Stage& r, int t) {
-    int rem = t;
-    const int tx = rem % p.tiles_x;
-    rem /= p.tiles_x;
-    const int ty = rem % p.tiles_y;
-    const int b = rem / p.tiles_y;
-    const int x0 = tx * TW, y0 = ty * TRB;
+  // Addresses: a load is [uniform tile base, kept in scalar registers and advanced tile by tile] + [a per-thread byte
+  // offset that does not depend on the tile, computed once] -- one instruction per load (scalar base + 32-bit vector
+  // offset) and no vector ALU work.  With the addresses formed per tile (tile decode by division, clamps, 64-bit
+  // multiply-adds per item: ~160-250 vector instructions per wave and tile at 4 cycles each) the three waves of a
+  // SIMD serialised on that arithmetic: in-kernel stamps had the LAST wave of a SIMD issue its loads 2 000 (<128, 32>)
+  // to 4 400 (<64, 64>) cycles after the barrier, 40-60 % of a tile's 5 100-6 800 cycles, with the matrix pipe waiting.
+  unsigned goff[S::NGS_], xoff[S::NXS_], xloff[S::NXS_];
 #pragma unroll
-    for (int i = 0; i < S::NGS_; ++i) {
-      const int g = min(tid + i * NTHREADS, S::NG - 1);
-      const int seg = g >> 2, q = g & 3;                         // seg = channel * 4 + tile row
-      const int o = min(o0 + (seg >> 2), p.cout - 1);
-      r.gv[i] = *reinterpret_cast<const u32x4*>(p.g16 + (size_t(b) * p.cout + o) * gplane +
-                                              size_t(y0 + (seg & 3)) * p.W + x0 + q * 8);
-    }
+  for (int i = 0; i < S::NGS_; ++i) {
+    const int g = min(tid + i * NTHREADS, S::NG - 1);
+    const int seg = g >> 2, q = g & 3;                           // seg = channel * 4 + tile row
+    const int o = min(o0 + (seg >> 2), p.cout - 1);
+    goff[i] = unsigned((size_t(o) * gplane + size_t(seg & 3) * p.W + q * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < S::NXS_; ++i) {
+    const int it = min(tid + i * NTHREADS, S::NX - 1);           // channel xc, halo row xr, 8-pixel group xq
+    const int xq = it & 3, xr = (it >> 2) % HRB, xc = it / (4 * HRB);
+    xoff[i] = unsigned((size_t(min(c0 + xc, p.cin - 1)) * xplane + size_t(xr) * p.wp + XPAD + xq * 8) * 2);
+    // One halo dword per item instead of two neighbour dwords: the four lanes xq = 0..3 of a row hold consecutive
+    // 8-pixel groups, so the left / right neighbour pixels of the inner groups come from the adjacent LANE at store
+    // time (DPP row_shr / row_shl) and only xq == 0 / xq == 3 fetch the pixels outside the 32-pixel tile row.  (Two
+    // plain neighbour loads got merged by hipcc with the 16-byte load into a misaligned pair whose registers were
+    // re-sorted right behind the loads: s_waitcnt vmcnt(4); v_mov ... -- a wait for the whole memory latency in
+    // front of every MFMA phase.)
+    xloff[i] = xq == 0 ? xoff[i] - 4u : (xq == 3 ? xoff[i] + 16u : xoff[i] + 4u * unsigned(xq));
+  }
+  // the tile the next load() call fetches: calls come in tile order t_begin, t_begin + 1, ...
+  int lx = t_begin % p.tiles_x, ly = (t_begin / p.tiles_x) % p.tiles_y, lb = t_begin / (p.tiles_x * p.tiles_y);
+  auto load = [&](Stage& r) {
+    const size_t gbase = (size_t(lb) * p.cout * gplane + size_t(ly * TRB) * p.W + size_t(lx * TW)) * 2;
+    const size_t xbase = (size_t(lb) * p.cin * xplane + size_t(ly * TRB) * p.wp + size_t(lx * TW)) * 2;
+    const unsigned char* gb = reinterpret_cast<const unsigned char*>(p.g16) + gbase;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x16) + xbase;
+#pragma unroll
+    for (int i = 0; i < S::NGS_; ++i) r.gv[i] = *reinterpret_cast<const u32x4*>(gb + goff[i]);
 #pragma unroll
     for (int i = 0; i < S::NXS_; ++i) {
-      const int it = min(tid + i * NTHREADS, S::NX - 1);         // channel xc, halo row xr, 8-pixel group xq
-      const int xq = it & 3, xr = (it >> 2) % HRB, xc = it / (4 * HRB);
-      const unsigned short* row = p.x16 + (size_t(b) * p.cin + min(c0 + xc, p.cin - 1)) * xplane +
-                                  size_t(y0 + xr) * p.wp + XPAD + x0 + xq * 8;
-      r.xv[i] = *reinterpret_cast<const u32x4*>(row);
-      // One halo dword per item instead of two neighbour dwords: the four lanes xq = 0..3 of a row hold consecutive
-      // 8-pixel groups, so the left / right neighbour pixels of the inner groups come from the adjacent LANE at store
-      // time (DPP row_shr / row_shl) and only xq == 0 / xq == 3 fetch the pixels outside the 32-pixel tile row.  (Two
-      // plain neighbour loads got merged by hipcc with the 16-byte load into a misaligned pair whose registers were
-      // re-sorted right behind the loads: s_waitcnt vmcnt(4); v_mov ... -- a wait for the whole memory latency in
-      // front of every MFMA phase.)
-      r.xl[i] = *reinterpret_cast<const unsigned*>(xq == 0 ? row - 2 : (xq == 3 ? row + 8 : row + 2 * xq));
+      r.xv[i] = *reinterpret_cast<const u32x4*>(xb + xoff[i]);
+      r.xl[i] = *reinterpret_cast<const unsigned*>(xb + xloff[i]);
+    }
+    if (++lx == p.tiles_x) {
+      lx = 0;
+      if (++ly == p.tiles_y) { ly = 0; ++lb; }
     }
   };
   static_assert(S::NX % NTHREADS == 0, "the DPP neighbour exchange in store() needs whole waves of x items");
@@ -789,19 +804,19 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_wgrad_bf16s_kernel(WgradPara
       }
     }
   };
-  if (t_begin < t_end) load(st0, t_begin);
-  if (t_begin + 1 < t_end) load(st1, t_begin + 1);
+  if (t_begin < t_end) load(st0);
+  if (t_begin + 1 < t_end) load(st1);
   for (int t = t_begin; t < t_end; t += 2) {
     ST_LDS_BARRIER();   // previous tile's MFMA phase is done with LDS
     store(st0);
     ST_LDS_BARRIER();
-    if (t + 2 < t_end) load(st0, t + 2);   // in flight during two MFMA phases
+    if (t + 2 < t_end) load(st0);          // tile t + 2: in flight during two MFMA phases
     mfma_tile();
     if (t + 1 < t_end) {
       ST_LDS_BARRIER();
       store(st1);
       ST_LDS_BARRIER();
-      if (t + 3 < t_end) load(st1, t + 3);
+      if (t + 3 < t_end) load(st1);        // tile t + 3
       mfma_tile();
     }
   }
@@ -964,14 +979,16 @@ extern "C" int st_conv3x3_wgrad(const float* x, const float* dy, const float* y_
 }
 
 // staged bf16 path: whole 4 x 32 pixel tiles, 16-B rows
-static bool wgrad_bf16_staged_ok(int cout, int H, int W) {
-  return cout != 3 && W % 32 == 0 && H % bf::TRB == 0;
+// one image's operand planes must stay below 4 GiB: the kernel adds 32-bit per-thread byte offsets to a scalar tile base
+static bool wgrad_bf16_staged_ok(int cout, int cin, int H, int W) {
+  return cout != 3 && W % 32 == 0 && H % bf::TRB == 0 && (long long)cout * H * W * 2 < (1LL << 32) &&
+         (long long)cin * (H + 2) * (W + 2 * bf::XPAD) * 2 < (1LL << 32);
 }
 static size_t align16(size_t bytes) { return (bytes + 15) & ~size_t(15); }
 
 extern "C" size_t st_conv3x3_wgrad_bf16_workspace_bytes(int n, int cout, int cin, int h, int w) {
   size_t bytes = align16(st_conv3x3_wgrad_workspace_bytes(n, cout, cin, h, w));
-  if (bytes == 0 || !wgrad_bf16_staged_ok(cout, h, w)) return bytes;
+  if (bytes == 0 || !wgrad_bf16_staged_ok(cout, cin, h, w)) return bytes;
   bytes += align16(size_t(n) * cout * sizeof(float));                                   // bias rows per image
   bytes += align16(size_t(n) * cout * h * w * sizeof(unsigned short));                   // G
   bytes += align16(size_t(n) * cin * (h + 2) * (w + 2 * bf::XPAD) * sizeof(unsigned short));   // Xp
@@ -999,7 +1016,7 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
   }
   ST_REQUIRE((long long)n * st::cdiv(W, TW) * st::cdiv(H, bf::TRB) <= 0x7fffffffLL,
              "st_conv3x3_wgrad_bf16: too many pixel tiles");
-  const bool staged = wgrad_bf16_staged_ok(cout, H, W) && (long long)n * cout <= 0x7fffffffLL &&
+  const bool staged = wgrad_bf16_staged_ok(cout, cin, H, W) && (long long)n * cout <= 0x7fffffffLL &&
                       (long long)n * cin <= 0x7fffffffLL && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(workspace) % 16 == 0;
   int sbo = BO, sci = CI;
@@ -1080,7 +1097,7 @@ extern "C" int st_conv3x3_wgrad_bf16(const float* x, const float* dy, const floa
 // Staged shapes only (W % 32 == 0, H % 4 == 0, cout != 3).
 extern "C" size_t st_conv3x3_wgrad_bf16_pre_workspace_bytes(int n, int cout, int cin, int h, int w) {
   size_t bytes = align16(st_conv3x3_wgrad_workspace_bytes(n, cout, cin, h, w));
-  if (bytes == 0 || !wgrad_bf16_staged_ok(cout, h, w)) return 0;
+  if (bytes == 0 || !wgrad_bf16_staged_ok(cout, cin, h, w)) return 0;
   bytes += align16(size_t(n) * cin * (h + 2) * (w + 2 * bf::XPAD) * sizeof(unsigned short));   // Xp
   return bytes;
 }
@@ -1097,8 +1114,8 @@ extern "C" int st_conv3x3_wgrad_bf16_pre(const void* x, int x_g8, const void* g1
   ST_REQUIRE(!dbias || (bias_slabs && n_bias_slabs > 0), "st_conv3x3_wgrad_bf16_pre: dbias needs the bias partial sums");
   const int up = upsample2x ? 1 : 0;
   const int H = hin << up, W = win << up;
-  ST_REQUIRE(wgrad_bf16_staged_ok(cout, H, W), "st_conv3x3_wgrad_bf16_pre: needs W %% 32 == 0, H %% 4 == 0, cout != 3 "
-             "(got %dx%d, cout=%d)", H, W, cout);
+  ST_REQUIRE(wgrad_bf16_staged_ok(cout, cin, H, W), "st_conv3x3_wgrad_bf16_pre: needs W %% 32 == 0, H %% 4 == 0, cout != 3 "
+             "and operand planes of one image below 4 GiB (got %dx%d, cout=%d, cin=%d)", H, W, cout, cin);
   ST_REQUIRE(!x_g8 || cin % 8 == 0, "st_conv3x3_wgrad_bf16_pre: a G8 x needs cin %% 8 == 0");
   ST_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(g16) % 16 == 0 &&
              reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "st_conv3x3_wgrad_bf16_pre: 16-byte aligned buffers expected");
