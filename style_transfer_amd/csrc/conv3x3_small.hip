@@ -17,6 +17,7 @@
 // it transparently when the shape fits (no upsample, no fused pool).
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -108,6 +109,146 @@ __global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(
         float v = acc[p][k];
         if (relu) v = fmaxf(v, 0.f);
         yb[size_t(co0 + k) * plane] = v;
+      }
+    }
+  }
+}
+
+// ---- cin == 3, cout <= 64 on the fp32 matrix pipe ------------------------------------------------
+// The same layer as conv3x3_cin_small_kernel as a GEMM with K = 27 (padded to 28 = 14 steps of
+// v_mfma_f32_32x32x2_f32, exact fp32 products accumulated in k order): D[cout][pixel] = sum_k W[cout][k] X[k][pixel],
+// k = channel * 9 + tap.  The vector-ALU form is bound by its weight reads (432 broadcast ds_read_b128 per thread);
+// here the 2 x 14 weight fragments of a lane stay in registers and the only operand traffic is one conflict-free
+// ds_read_b32 per MFMA.
+//   * persistent blocks of 4 waves (4 per CU), tile = 4 rows x 128 columns x 64 channels; wave w owns row w and walks
+//     its eight 32-channel x 32-column accumulator tiles ONE at a time (see the loop): 16 accumulator registers;
+//   * the (4 + 2) x (128 + 2) halo of the 3 input channels is staged per tile (9.5 KB; padding resolved there), the
+//     next tile's halo requested before the current tile's MFMAs.
+// B=16, 512 x 512: 310 -> 266 us (45 -> 53 % of the HBM peak for its 1.07 GB of output); grid sweep 512 / 768 / 1024 /
+// 2048 / one block per tile: 295 / 277 / 266 / 282 / 283 us.  ST_CIN3_VALU=1 selects the vector-ALU kernel.
+constexpr int MTW = 128, MTH = 4;                  // tile: 4 rows x 128 columns (wave = row, accumulator tile = 32 columns)
+constexpr int MHC = MTW + 4;                       // halo row stride (MTW + 2 used)
+constexpr int MPLANE = (MTH + 2) * MHC;
+
+__global__ __launch_bounds__(256, 4) void conv3x3_cin3_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, int H, int W, int cout, int cout_pad, int pad_zero, int relu,
+    int tiles_x, int tiles_y, int ntiles) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  constexpr int NH = 3 * (MTH + 2) * (MTW + 2), NHP = (NH + 255) / 256;      // halo elements, per thread
+  __shared__ float xs[3 * MPLANE];
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 32];
+  __shared__ float bsh[64];
+  if (threadIdx.x < 64) bsh[threadIdx.x] = (bias && int(threadIdx.x) < cout) ? bias[threadIdx.x] : 0.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const size_t plane = size_t(H) * W;
+
+  // halo element i of this thread: position (r, cc) of channel c <- pixel (y0 + r - 1, x0 + cc - 1)
+  int hpk[NHP];       // (channel << 16) | (row << 8) | column
+#pragma unroll
+  for (int j = 0; j < NHP; ++j) {
+    const int i = min(tid + j * 256, NH - 1);
+    const int c = i / ((MTH + 2) * (MTW + 2)), rem = i - c * ((MTH + 2) * (MTW + 2));
+    const int r = rem / (MTW + 2);
+    hpk[j] = (c << 16) | (r << 8) | (rem - r * (MTW + 2));
+  }
+  float hv[NHP];
+  // a persistent block walks tiles blockIdx.x, + gridDim.x, ...: the halo of the next tile is requested before the
+  // MFMAs and the stores of the current one
+  auto load_halo = [&](int t) {
+    const int tx = t % tiles_x;
+    const int rest = t / tiles_x;
+    const int ty = rest % tiles_y, b = rest / tiles_y;
+    const float* xb = x + size_t(b) * 3 * plane;
+#pragma unroll
+    for (int j = 0; j < NHP; ++j) {
+      const int gy = ty * MTH + ((hpk[j] >> 8) & 255) - 1, gx = tx * MTW + (hpk[j] & 255) - 1;
+      const bool keep = (gy >= 0 && gy < H && gx >= 0 && gx < W) || !pad_zero;
+      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      const float v = xb[(hpk[j] >> 16) * plane + size_t(cy) * W + cx];
+      hv[j] = keep ? v : 0.f;
+    }
+  };
+  int tile = blockIdx.x;
+  load_halo(tile);
+
+  // weight fragments: step s of lane (li, lh) = W[cout = mt * 32 + li][k = 2 s + lh]; k = 27 and channels >= cout are zero
+  float wa[2][14];
+#pragma unroll
+  for (int s2 = 0; s2 < 14; ++s2) {
+    const int k = 2 * s2 + lh;
+    const int c = min(k / 9, 2), tap = k - (k / 9) * 9;
+    const bool real = k < 27;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int co = mt * 32 + li;
+      wa[mt][s2] = (real && co < cout) ? wp[size_t((real ? tap : 0) * KC + c) * cout_pad + co] : 0.f;
+    }
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const float* bp = xs + wave * MHC + li;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x;
+    const int rest = tile / tiles_x;
+    const int ty = rest % tiles_y, b = rest / tiles_y;
+    const int x0 = tx * MTW, y0 = ty * MTH;
+    __syncthreads();                       // the previous tile's operand reads are done
+#pragma unroll
+    for (int j = 0; j < NHP; ++j)
+      if (NH % 256 == 0 || tid + j * 256 < NH)
+        xs[(hpk[j] >> 16) * MPLANE + ((hpk[j] >> 8) & 255) * MHC + (hpk[j] & 255)] = hv[j];
+    __syncthreads();
+    if (tile + int(gridDim.x) < ntiles) load_halo(tile + int(gridDim.x));
+
+    // One 32-channel x 32-column accumulator tile at a time (a chain of 14 MFMAs), its LDS-patch transpose and its four
+    // 16-byte-per-lane stores right behind it: 16 accumulator registers instead of 128, so four blocks share a CU and
+    // one wave's stores drain under the other waves' MFMAs.  (With all eight tiles of a wave held in registers -- 229
+    // registers, two blocks per CU -- the phases simply added up: 313 us = 107 of MFMAs + 125 of stores + 35 of halo
+    // loads + the rest, measured by leaving each out.)
+    // An accumulator register is 32 consecutive x of one channel row; stored as is that is 16 dword-store
+    // instructions per tile and the store ISSUE binds, hence the transpose: 8 lanes cover one 128-B row segment, an
+    // instruction writes 8 channel rows.  (w % 4 == 0, y 16-B aligned: host check)
+    // operand offsets of the two k of a step are compile-time constants selected by lh
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int yw = y0 + wv;
+    float* pt = patch + wave * (32 * 32);
+    // lh made opaque per tile: the 14 operand-offset selects (and nothing else) are redone per tile instead of being
+    // hoisted into 14 registers; the stores are [scalar base] + [one per-lane byte offset] for the same reason
+    int lho = lh;
+    asm volatile("" : "+v"(lho));
+    const unsigned st_off = unsigned((size_t(lane >> 3) * plane + (lane & 7) * 4) * sizeof(float));
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 14; ++s2) {
+          const int k0 = 2 * s2, k1 = 2 * s2 + 1;
+          const int o0 = (k0 / 9) * MPLANE + ((k0 % 9) / 3) * MHC + (k0 % 9) % 3;
+          const int o1 = k1 < 27 ? (k1 / 9) * MPLANE + ((k1 % 9) / 3) * MHC + (k1 % 9) % 3 : 0;
+          const float bv = bp[(lho ? o1 : o0) + nt * 32];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[mt][s2], bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[r] + bsh[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+          if (relu) v = fmaxf(v, 0.f);
+          pt[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(pt + (q * 8 + (lane >> 3)) * 32 + (lane & 7) * 4);
+          const int cg = mt * 32 + q * 8;                      // + lane / 8: the same side of cout (a multiple of 16)
+          unsigned char* base = reinterpret_cast<unsigned char*>(y + (size_t(b) * cout + cg) * plane + size_t(yw) * W +
+                                                                 x0 + nt * 32);
+          if (cg < cout && yw < H && x0 + nt * 32 + (lane & 7) * 4 < W)
+            *reinterpret_cast<f32x4*>(base + st_off) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one tile's registers at a time
       }
     }
   }
@@ -582,9 +723,16 @@ bool conv3x3_small_fwd(const float* x, const float* w_packed, const float* bias,
   if (cin == 3 && cout <= ACO && cout % 16 == 0) {
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 16);
     const long long blocks = (long long)n * tiles_x * tiles_y;
-    if (blocks > 0x7fffffffLL) return false;
-    hipLaunchKernelGGL(conv3x3_cin_small_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, x, w_packed, bias, y,
-                       h, w, cout, cout_pad, pad_zero, relu, tiles_x, tiles_y);
+    const int mtx = cdiv(w, MTW), mty = cdiv(h, MTH);
+    const long long mblocks = (long long)n * mtx * mty;
+    if (blocks > 0x7fffffffLL || mblocks > 0x7fffffffLL) return false;
+    // ST_CIN3_VALU=1: the vector-ALU form (A/B measurements)
+    if (getenv("ST_CIN3_VALU") == nullptr && w % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0)
+      hipLaunchKernelGGL(conv3x3_cin3_mfma_kernel, dim3((unsigned)std::min<long long>(mblocks, 1024)), dim3(256), 0, s, x,
+                         w_packed, bias, y, h, w, cout, cout_pad, pad_zero, relu, mtx, mty, (int)mblocks);
+    else
+      hipLaunchKernelGGL(conv3x3_cin_small_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, x, w_packed, bias, y,
+                         h, w, cout, cout_pad, pad_zero, relu, tiles_x, tiles_y);
     *rc = check_launch("st_conv3x3_fwd(cin=3)");
     return true;
   }
