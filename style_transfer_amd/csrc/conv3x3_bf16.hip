@@ -534,6 +534,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
     }                                                                                      \
     if (MORE1_) { ST_BARRIER_DRAIN_XG(((chunk_) + 1) & 1); } else { ST_BARRIER_DRAIN(); }  \
   }
+#define ST_CHUNK_PIPE_R(chunk_, MORE1_, MORE2_)                                            \
+  {                                                                                        \
+    ST_READ_TAP_R(chunk_, 0, 0);                                                           \
+    if (MORE1_) ST_ISSUE_W((chunk_) + 1);                                                  \
+    asm volatile("" ::: "memory");                                                         \
+    ST_SLICE(chunk_, 0, MORE1_, MORE2_);                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                        \
+      if (t < 8) ST_READ_TAP_R(chunk_, t + 1, (t + 1) & 1);                                \
+      ST_MFMA_TAP_R(t, t & 1);                                                             \
+      ST_SLICE(chunk_, t + 1, MORE1_, MORE2_);                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+    }                                                                                      \
+    if (MORE2_) { ST_BARRIER_KEEP_LOADS(); } else { ST_BARRIER_DRAIN(); }                  \
+  }
 #define ST_CHUNK_DMA(chunk_, MORE1_)                                                       \
   {                                                                                        \
     ST_READ_TAP(chunk_, 0, 0);                                                             \
@@ -616,6 +631,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       for (; chunk + 1 < nch; ++chunk) ST_CHUNK_DMA(chunk, true);
       ST_CHUNK_DMA(chunk, false);
     }
+  } else if constexpr (PIPE && !SPLIT) {
+    bf16x8 pa[2][MT], pbr[3][NT + 2];
+    int chunk = 0;
+    for (; chunk + 2 < nch; ++chunk) ST_CHUNK_PIPE_R(chunk, true, true);
+    if (chunk + 1 < nch) { ST_CHUNK_PIPE_R(chunk, true, false); ++chunk; }
+    ST_CHUNK_PIPE_R(chunk, false, false);
   } else if constexpr (PIPE) {
     bf16x8 pa[2][MT], pb[2][NT], pal[SPLIT ? 2 : 1][MT], pbl[SPLIT ? 2 : 1][NT];
     int chunk = 0;
@@ -1138,6 +1159,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
 #undef ST_MFMA_TAP
 #undef ST_SLICE
 #undef ST_CHUNK_PIPE
+#undef ST_CHUNK_PIPE_R
+#undef ST_CHUNK_DMA_R
+#undef ST_READ_TAP_R
+#undef ST_MFMA_TAP_R
 #undef ST_ISSUE_W
 #undef ST_ISSUE_XG
 #undef ST_CHUNK_DMA
