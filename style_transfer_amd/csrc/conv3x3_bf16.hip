@@ -1377,6 +1377,12 @@ extern "C" int st_conv3x3_pack_weights_bf16x3(const float* w_oihw, void* w_packe
   return pack_weights_bf16_impl(w_oihw, w_packed, cout, cin, transpose_flip, 2, stream);
 }
 
+namespace st {
+// csrc/conv3x3_bf16_cin3.hip
+bool conv3x3_bf16_cin3_fwd(const float* x, const void* w_packed, const float* bias, void* y, bool y_g8, int n, int cin,
+                           int h, int w, int cout, int cout_pad, int pad_zero, int relu, hipStream_t s, int* rc);
+}  // namespace st
+
 static int conv3x3_fwd_bf16_impl(const float* x, const void* w_packed, const float* bias, float* y,
                                  int n, int cin, int hin, int win, int cout, int upsample2x,
                                  int pad_mode, int relu, int pool, st_stream_t stream, bool split = false) {
@@ -1397,6 +1403,12 @@ static int conv3x3_fwd_bf16_impl(const float* x, const void* w_packed, const flo
   p.nchunks = st::cdiv(cin, KC);
   p.pad_zero = pad_mode == ST_PAD_ZERO;
   p.relu = relu ? 1 : 0;
+  if (!split && !pool && !upsample2x) {          // the 3-channel first layer: csrc/conv3x3_bf16_cin3.hip
+    int rc = ST_OK;
+    if (st::conv3x3_bf16_cin3_fwd(x, w_packed, bias, y, false, n, cin, hin, win, cout, p.cout_pad, p.pad_zero, p.relu,
+                                  (hipStream_t)stream, &rc))
+      return rc;
+  }
   return dispatch_conv<false>(p, (hipStream_t)stream, split);
 }
 
@@ -1445,6 +1457,12 @@ static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, co
   p.pad_zero = pad_mode == ST_PAD_ZERO;
   p.relu = relu ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
+  if (!x_g8 && y_g8 && !split && !pool && !upsample2x && !ogate && !pool_codes) {
+    int rc = ST_OK;
+    if (st::conv3x3_bf16_cin3_fwd((const float*)x, w_packed, bias, y, true, n, cin, hin, win, cout, p.cout_pad,
+                                  p.pad_zero, p.relu, s, &rc))
+      return rc;
+  }
   if (split) return launch_conv_g8<1, 4, 2, 4, true>(p, x_g8 != 0, y_g8 != 0, s);   // 64 ch x (16 rows x 32)
   if (cout > 64) return launch_conv_g8<2, 4, 2, 4>(p, x_g8 != 0, y_g8 != 0, s);   // 128 ch x (16 rows x 32)
   if (cout > 32) return launch_conv_g8<2, 4, 1, 8>(p, x_g8 != 0, y_g8 != 0, s);   //  64 ch x (32 rows x 32)

@@ -276,5 +276,8 @@ def test_train_step_bf16_gradients_with_pinned_gates():
     for name, k, e in rows:
         # the top layer's weight gradient of the variation term multiplies TVLoss's Laplacian-like dy (alternating
         # signs) with the top layer's INPUT, itself 17 bf16 convolutions deep: a cancelling sum over operands that
-        # carry rounding-boundary ulps (measured 1.6e-2); everything else stays under 1e-2
-        assert e <= (3e-2 if (name, k) == ("variation", "decoder.28.weight") else 1e-2), (name, k, e)
+        # carry rounding-boundary ulps (measured 1.6e-2).  Everything else: the histogram term's weight gradients sit
+        # at the level of the mode itself (bf16 eps = 3.9e-3, nine rounded layers): 0.7-0.9e-2 with the TAIL form of
+        # conv1_1, 0.7-1.14e-2 with the K = 27 form (a different fp32 accumulation order in the first layer moves
+        # roundings everywhere downstream); the bound is half the mode's stated tolerance (3e-2), not the measurement
+        assert e <= (3e-2 if (name, k) == ("variation", "decoder.28.weight") else 1.5e-2), (name, k, e)
