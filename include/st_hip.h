@@ -303,6 +303,13 @@ int st_maxpool2x2_fwd_g8(const float* x, void* y_g8, int n, int c, int h, int w,
 int st_conv3x3_pool_fwd_bf16_g8_codes(const void* x, int x_g8, const void* w_packed, const float* bias,
                                       void* y_pooled_g8, void* codes, int n, int cin, int hin, int win, int cout,
                                       int pad_mode, int relu, st_stream_t stream);
+/* A loss tap that feeds a pool (torchvision vgg19 conv1_2 / conv2_2 under IntermediateLayerGetter, trainer.py:165-199,
+ * 446-457): y = the fp32 NCHW activation the loss reads, y_pooled_g8 = its 2x2 max pool in G8 [n][cout/8][h/2][w/2][8]
+ * for the next conv -- one launch instead of st_conv3x3_fwd_bf16_g8 + st_maxpool2x2_fwd_g8 (same bits).  x is G8
+ * (cin % 16 == 0); even h and w; cout % 8 == 0. */
+int st_conv3x3_fwd_bf16_g8_tap_pool(const void* x_g8, const void* w_packed, const float* bias, float* y,
+                                    void* y_pooled_g8, int n, int cin, int hin, int win, int cout, int pad_mode,
+                                    int relu, st_stream_t stream);
 /* ... and its backward half: the G8 gradient w.r.t. the pooled activation [n][c/8][h/2][w/2][8] routed to the
  * position the code names where the code's bit 2 is set, zeros elsewhere -> G8 [n][c/8][h][w][8], the (already ReLU-
  * gated) operand of st_conv3x3_dgrad_bf16_g8.  Same values as st_grad_join_g8(chain_pooled, x_gate) on the

@@ -84,6 +84,8 @@ SIGNATURES = {
     "st_maxpool2x2_fwd_g8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_conv3x3_pool_fwd_bf16_g8_codes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "st_conv3x3_fwd_bf16_g8_tap_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                c_int, c_int, c_int, c_int, c_void_p]),
     "st_grad_pool_codes_g8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "st_adain_fwd_dev_eps": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float,

@@ -38,6 +38,9 @@ AFFINE_TAPS = True          # ST_NO_AFFINE_TAPS=1 (read in loss_network) keeps t
 # pool-input layers nobody captures: conv + ReLU + pool in one launch, winner codes for the backward
 # (ops.conv3x3_pool_g8_codes); ST_NO_POOL_CODES=1 keeps the fp32 activation + maxpool2x2_g8 + pooled join (A/B, tests)
 POOL_CODES = os.environ.get("ST_NO_POOL_CODES") is None
+# captured pool-input layers (loss taps): the fp32 tap and the pooled G8 input of the next conv from one launch
+# (ops.conv3x3_g8_tap_pool); ST_NO_TAP_POOL=1 keeps conv -> st_maxpool2x2_fwd_g8
+TAP_POOL = os.environ.get("ST_NO_TAP_POOL") is None
 
 
 def lazy_affine_grad(tap: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
@@ -106,6 +109,7 @@ class VGGChainFunction(torch.autograd.Function):
         meta = []                       # per unit: dict(kind, idx, ..., slot of the saved tensor)
         cur = x.contiguous()
         fused_pool = False              # the conv unit before this pool unit already pooled (winner codes saved)
+        pooled_ready = None             # ... or wrote the pooled G8 tensor next to its fp32 tap
         for k, u in enumerate(units):
             if u[0] == "pool":
                 idx = u[1]
@@ -114,6 +118,10 @@ class VGGChainFunction(torch.autograd.Function):
                     meta.append({"kind": "pool", "idx": idx, "fused": True})
                     continue
                 c, h, w = int(cur.shape[1]), int(cur.shape[2]), int(cur.shape[3])
+                if pooled_ready is not None:
+                    cur, pooled_ready = pooled_ready, None
+                    meta.append({"kind": "pool", "idx": idx, "h": h, "w": w})
+                    continue
                 if idx not in post and k + 1 < len(units) and h % 2 == 0 and w % 2 == 0 and c % 16 == 0:
                     cur = ops.maxpool2x2_g8(cur)         # nobody captures it: straight into the next conv's input form
                 else:
@@ -151,7 +159,11 @@ class VGGChainFunction(torch.autograd.Function):
                     meta.append(m)
                     fused_pool = True
                     continue
-                y = ops.conv3x3_g8(cur, wp, bias, cout, False, ops.PAD_ZERO, relu=True, pool=False, y_g8=y_g8)
+                if (TAP_POOL and captured and pool_next and units[k + 1][1] not in post and k + 2 < len(units)
+                        and cout % 16 == 0 and hh % 2 == 0 and ww % 2 == 0 and ops.is_g8(cur)):
+                    y, pooled_ready = ops.conv3x3_g8_tap_pool(cur, wp, bias, cout, ops.PAD_ZERO, relu=True)
+                else:
+                    y = ops.conv3x3_g8(cur, wp, bias, cout, False, ops.PAD_ZERO, relu=True, pool=False, y_g8=y_g8)
                 m["g8"] = y_g8
                 if captured:
                     outs[("post", idx)] = y

@@ -69,6 +69,7 @@ struct ConvParams {
   // [n][c/8][Ho/2][Wo/2][8] -- bits 0-1 = the window position (row-major scan order) that holds the maximum under the
   // max-pool backward's tie rule (the first maximum wins), bit 2 = that maximum is > 0 (the ReLU gate)
   unsigned* pcodes = nullptr;
+  void* y2 = nullptr;      // fp32-output G8-input form only: the 2 x 2 max pool of the activation, in G8 (see the epilogue)
   int ldo;                 // output row stride in floats (Wo, or Wo rounded up to 4 in the padded workspace)
   int shift;               // output pixel (oy, ox) is centred on input pixel (oy - shift, ox - shift)
   int cout_pad, nchunks;
@@ -1140,6 +1141,61 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_bf16_kernel(ConvParams p)
       }
     }
   }
+  // Second output of a loss tap that feeds a pool (st_conv3x3_fwd_bf16_g8_tap_pool): the 2 x 2 max pool of the
+  // activation just written, in G8 -- the next conv's input form -- straight from the accumulators (row pairs are two
+  // accumulator tiles of this wave, column pairs neighbouring lanes; rounding is monotonic, so max-then-round equals
+  // the pool of the rounded activation).  Even Ho, Wo (host check).
+  if constexpr (XG && !YG && !SPLIT && EPI == 0 && NT % 2 == 0) {
+    if (p.y2) {
+      asm volatile("" ::: "memory");         // the fp32 epilogue's patch reads are done (same wave-private region)
+      unsigned* pp = reinterpret_cast<unsigned*>(smem16 + wave * 256);
+      const u32x4* pp16 = reinterpret_cast<const u32x4*>(pp);
+      u32x4* yg2 = reinterpret_cast<u32x4*>(p.y2);
+      const int cgroups = p.cout >> 3, Hy = p.Ho >> 1, Wy = p.Wo >> 1;
+      const size_t plane_y = size_t(Hy) * Wy;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cbase = m0 + wm * (MT * 32) + mt * 32;
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          bv[r] = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt + 1 < NT; nt += 2) {
+          const int yy = y0 + wp * NT + nt;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = fmaxf(acc[mt][nt][q * 4 + j], acc[mt][nt + 1][q * 4 + j]);
+              v = fmaxf(v, __shfl_xor(v, 1, 64));
+              v += bv[q * 4 + j];
+              if (p.relu) v = fmaxf(v, 0.f);
+              h[j] = (__bf16)v;
+            }
+            if (!(li & 1)) {
+              const u32x2 hv = __builtin_bit_cast(u32x2, h);
+              pp[((li >> 1) * 4 + q) * 4 + lh * 2 + 0] = hv[0];
+              pp[((li >> 1) * 4 + q) * 4 + lh * 2 + 1] = hv[1];
+            }
+          }
+          asm volatile("" ::: "memory");
+          {
+            const int q = lane >> 4, px = lane & 15;
+            const int cg = (cbase >> 3) + q;
+            const bool ok = cg < cgroups && yy < p.Ho && x0 + 2 * px < p.Wo;
+            const size_t o = (size_t(b) * cgroups + cg) * plane_y + size_t(yy >> 1) * Wy + (x0 >> 1) + px;
+            const u32x4 v = pp16[px * 4 + q];
+            if (ok) yg2[o] = v;
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+  }
   if (!PERSIST || !has_next) break;
   tile += int(gridDim.x);
   b = nb; m0 = nm0; x0 = nx0; y0 = ny0; xg = nxg; xoob = nxoob;
@@ -1427,7 +1483,7 @@ extern "C" int st_conv3x3_pool_fwd_bf16(const float* x, const void* w_packed, co
 static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,
                                int y_g8, int n, int cin, int hin, int win, int cout, int upsample2x,
                                int pad_mode, int relu, int pool, st_stream_t stream, bool split,
-                               const void* ogate = nullptr, void* pool_codes = nullptr) {
+                               const void* ogate = nullptr, void* pool_codes = nullptr, void* y2_pooled = nullptr) {
   ST_REQUIRE(x && w_packed && y, "st_conv3x3_fwd_bf16_g8: null pointer");
   ST_REQUIRE(n > 0 && cin > 0 && cout > 0 && hin > 0 && win > 0,
              "st_conv3x3_fwd_bf16_g8: bad dims n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, hin, win);
@@ -1448,6 +1504,7 @@ static int conv3x3_fwd_g8_impl(const void* x, int x_g8, const void* w_packed, co
   p.x = (const float*)x; p.gate = nullptr; p.wp = (const u32x4*)w_packed; p.bias = bias; p.y = (float*)y;
   p.ogate = (const u32x4*)ogate;
   p.pcodes = (unsigned*)pool_codes;
+  p.y2 = y2_pooled;
   p.n = n; p.cin = cin; p.hs = hin; p.ws = win; p.cout = cout;
   p.up = upsample2x ? 1 : 0;
   p.H = hin << p.up; p.W = win << p.up;
@@ -1488,6 +1545,20 @@ extern "C" int st_conv3x3_pool_fwd_bf16_g8_codes(const void* x, int x_g8, const 
              "st_conv3x3_pool_fwd_bf16_g8_codes: even h and w expected (got %dx%d)", hin, win);
   return conv3x3_fwd_g8_impl(x, x_g8, w_packed, bias, y_pooled_g8, 1, n, cin, hin, win, cout, 0, pad_mode, relu, 1,
                              stream, false, nullptr, codes);
+}
+
+// A loss tap that feeds a pool (the loss VGG's conv1_2 / conv2_2 at the default taps, trainer.py:446-457): the fp32
+// NCHW activation the loss reads AND its 2 x 2 max pool in G8 for the next conv, from one launch -- instead of
+// st_maxpool2x2_fwd_g8 reading the fp32 activation back (805 MB per loss-VGG pass at B=8, 512 x 512).
+extern "C" int st_conv3x3_fwd_bf16_g8_tap_pool(const void* x_g8, const void* w_packed, const float* bias, float* y,
+                                               void* y_pooled_g8, int n, int cin, int hin, int win, int cout,
+                                               int pad_mode, int relu, st_stream_t stream) {
+  ST_REQUIRE(y_pooled_g8 && reinterpret_cast<uintptr_t>(y_pooled_g8) % 16 == 0,
+             "st_conv3x3_fwd_bf16_g8_tap_pool: y_pooled_g8 must be 16-byte aligned");
+  ST_REQUIRE(hin > 0 && win > 0 && hin % 2 == 0 && win % 2 == 0 && cout % 8 == 0,
+             "st_conv3x3_fwd_bf16_g8_tap_pool: even h and w and cout %% 8 == 0 expected (got %dx%d, cout=%d)", hin, win, cout);
+  return conv3x3_fwd_g8_impl(x_g8, 1, w_packed, bias, y, 0, n, cin, hin, win, cout, 0, pad_mode, relu, 0, stream, false,
+                             nullptr, nullptr, y_pooled_g8);
 }
 
 extern "C" int st_conv3x3_fwd_bf16x3_g8(const void* x, int x_g8, const void* w_packed, const float* bias, void* y,

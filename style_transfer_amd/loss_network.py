@@ -219,6 +219,7 @@ class VGG19FeatureExtractor(nn.Module):
         channel-group layout G8 (ops.conv3x3_g8, LDS-DMA staged, zero padding patched after the copy), with the
         floor-mode 2x2 pool fused into its epilogue when the size is even (floor == ceil there); captured tensors
         are fp32 NCHW as always.  Same bits as the fp32-activation kernels."""
+        from . import autograd_vgg
         want = {i for s in sets for i in s}
         pre: Dict[int, torch.Tensor] = {}
         post: Dict[int, torch.Tensor] = {}
@@ -266,6 +267,13 @@ class VGG19FeatureExtractor(nn.Module):
                 int(x.shape[-2] if ops.is_g8(x) or ops.is_g8_pair(x) else x.shape[-1])
             pool_next = idx + 2 <= last_all and self.layout[idx + 2][0] == "pool"
             fuse_pool = pool_next and not captured and (idx + 2) not in want and h % 2 == 0 and w % 2 == 0
+            if (autograd_vgg.TAP_POOL and compute == "bf16" and captured and pool_next and (idx + 2) not in want
+                    and idx + 3 <= last_all and ops.is_g8(x) and h % 2 == 0 and w % 2 == 0 and cout % 16 == 0):
+                # a tap that feeds a pool: the fp32 tap and the next conv's pooled G8 input from one launch
+                y, x = ops.conv3x3_g8_tap_pool(x, wp, bias, cout, ops.PAD_ZERO, relu=True)
+                post[idx] = post[idx + 1] = y
+                idx += 3                                    # conv + ReLU + pool
+                continue
             y_g8 = not captured and cout % 8 == 0 and (not pool_next or fuse_pool) and idx + 2 <= last_all
             x = ops.conv3x3_g8(x, wp, bias, cout, False, ops.PAD_ZERO, relu=True, pool=fuse_pool, y_g8=y_g8)
             if not y_g8:

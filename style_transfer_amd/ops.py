@@ -296,6 +296,31 @@ def conv3x3_pool_g8_codes(x: torch.Tensor, w_packed: torch.Tensor, bias: Optiona
     return y, codes
 
 
+def conv3x3_g8_tap_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+                        pad_mode="zero", relu: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(fp32 NCHW activation, its 2x2 max pool in G8) of a bf16-mode conv with a G8 input, one launch
+    (st_conv3x3_fwd_bf16_g8_tap_pool): a loss tap whose next layer is a pool.  Even h and w."""
+    lib = _lib.load()
+    assert is_g8(x) and x.is_contiguous()
+    n, cin, h, w = int(x.shape[0]), int(x.shape[1]) * 8, int(x.shape[2]), int(x.shape[3])
+    assert h % 2 == 0 and w % 2 == 0 and cout % 8 == 0
+    assert conv_family(w_packed, cout, cin) == "bf16", "conv3x3_g8_tap_pool needs bf16-packed weights"
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    yp = torch.empty((n, cout // 8, h // 2, w // 2, 8), dtype=torch.bfloat16, device=x.device)
+    ev = None
+    if KERNEL_TIMER.enabled:
+        ev = KERNEL_TIMER.record(conv_kernel_name(cout, "bf16"), 2.0 * n * h * w * cin * cout * 9,
+                                 float(x.numel() * 2 + y.numel() * 4 + yp.numel() * 2))
+    _lib.check(lib.st_conv3x3_fwd_bf16_g8_tap_pool(
+        _lib.dev_ptr(x, "x", torch.bfloat16), _lib.dev_ptr(w_packed, "w_packed", w_packed.dtype),
+        _lib.dev_ptr(bias, "bias") if bias is not None else None, _lib.dev_ptr(y, "y"),
+        _lib.dev_ptr(yp, "y_pooled", torch.bfloat16), n, cin, h, w, cout, _pad_code(pad_mode), int(relu),
+        _lib.stream_ptr()), "st_conv3x3_fwd_bf16_g8_tap_pool")
+    if ev is not None:
+        ev.record()
+    return y, yp
+
+
 def grad_pool_codes_g8(g_pooled: torch.Tensor, codes: torch.Tensor) -> torch.Tensor:
     """The G8 gradient w.r.t. a pooled activation routed through conv3x3_pool_g8_codes' winner codes
     (st_grad_pool_codes_g8): G8 [n, c/8, 2h, 2w, 8], ReLU gate included."""

@@ -339,3 +339,47 @@ def test_pool_codes_chain_is_bit_identical_to_the_fp32_pool_input_form(sets, n, 
         assert torch.equal(a, b)
     assert float(ref_grad.abs().max()) > 0
     assert torch.equal(got_grad, ref_grad)
+
+
+# ---- a loss tap that feeds a pool: fp32 tap + pooled G8 from one launch ----------------------------------------------
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (2, 64, 64, 32, 64),          # conv1_2's form (the 64-channel tile)
+    (1, 128, 128, 48, 40),        # conv2_2's form, partial pixel tiles
+    (1, 16, 32, 34, 6),           # the 32-channel tile
+    (1, 64, 48, 20, 36),          # a channel tail inside the last tile
+])
+def test_conv_tap_pool_dual_output(ops, n, cin, cout, h, w):
+    x = ops.to_g8(torch.relu(_rand((n, cin, h, w), 71)))
+    wt = _rand((cout, cin, 3, 3), 72, 0.05)
+    bias = _rand((cout,), 73, 0.1)
+    wp = ops.pack_conv3x3_weights(wt, False, "bf16")
+    ref = ops.conv3x3_g8(x, wp, bias, cout, False, ops.PAD_ZERO, relu=True, pool=False, y_g8=False)
+    y, yp = ops.conv3x3_g8_tap_pool(x, wp, bias, cout, ops.PAD_ZERO, relu=True)
+    assert torch.equal(y, ref)
+    assert torch.equal(yp, ops.maxpool2x2_g8(ref))
+
+
+def test_tap_pool_passes_are_bit_identical_to_the_separate_pool():
+    from style_transfer_amd import autograd_vgg, precision
+    sets = [[21], [2, 7, 14, 19, 25]]
+    net = _extractor(sets)
+    x0 = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(10)).cuda()
+
+    def run(tap_pool):
+        autograd_vgg.TAP_POOL = tap_pool
+        with precision.compute_dtype("bf16"), torch.no_grad():
+            plain = [t for s in net.forward_multi(x0, sets) for t in s]
+        x = x0.clone().requires_grad_(True)
+        with precision.compute_dtype("bf16"):
+            flat = [t for s in net.forward_multi(x, sets) for t in s]
+            sum((t * t).mean() for t in flat).backward()
+        return plain, [t.detach() for t in flat], x.grad
+
+    try:
+        ref = run(False)
+        got = run(True)
+    finally:
+        autograd_vgg.TAP_POOL = True
+    for a, b in zip(got[0] + got[1], ref[0] + ref[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(got[2], ref[2])
