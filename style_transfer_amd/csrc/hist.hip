@@ -17,6 +17,8 @@
 #include <atomic>
 #include <cstdint>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -100,14 +102,33 @@ __global__ __launch_bounds__(NT) void hist_prep_kernel(const float* __restrict__
 // and the rational / exponential of it in fp32 (1 / (1 + q) by v_rcp_f32, 1 ulp): <= 3e-7 relative per weight, the
 // size of the error the fp32 MFMA accumulation of the 22 500 weights has anyway.  (All-fp64 weights with their fp64
 // division made hist_accum_kernel arithmetic-bound: 88 us for 0.55 GFLOP of matrix work at B=8.)
+template <int METHOD>
 __device__ __forceinline__ float kweight(float u, double bin, const HistParams& hp) {
   const double d = fabs(double(u) - bin);
-  if (hp.method == ST_HIST_THRESHOLDING) return d <= hp.thr ? 1.f : 0.f;
+  if constexpr (METHOD == ST_HIST_THRESHOLDING) return d <= hp.thr ? 1.f : 0.f;
   const float df = float(d);
   const float q = df * df * float(hp.inv_sigma2);
-  if (hp.method == ST_HIST_RBF) return expf(-q);
+  if constexpr (METHOD == ST_HIST_RBF) return expf(-q);
   return __builtin_amdgcn_rcpf(1.0f + q);
 }
+// the 16 bins x 2 weights of a lane's pixel for a chunk, with the method resolved ONCE per chunk: with the (uniform)
+// method test inside every weight the fill was a chain of 32 x 3 scalar branches with one weight's latency exposed
+// between each pair
+#define ST_HIST_FILL(DST_A, DST_B, SCALE_A)                                                       \
+  {                                                                                               \
+    auto fill_ = [&](auto m_) {                                                                   \
+      constexpr int M_ = decltype(m_)::value;                                                     \
+      _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                            \
+        const int bin = wave * 16 + k;                                                            \
+        const double bc = hp.bins[bin];                                                           \
+        DST_A[lane * LS + bin] = ok ? (SCALE_A) * kweight<M_>(u, bc, hp) : 0.f;                   \
+        DST_B[lane * LS + bin] = ok ? kweight<M_>(v, bc, hp) : 0.f;                               \
+      }                                                                                           \
+    };                                                                                            \
+    if (hp.method == ST_HIST_THRESHOLDING) fill_(std::integral_constant<int, ST_HIST_THRESHOLDING>());   \
+    else if (hp.method == ST_HIST_RBF) fill_(std::integral_constant<int, ST_HIST_RBF>());         \
+    else fill_(std::integral_constant<int, ST_HIST_INVERSE_QUADRATIC>());                         \
+  }
 
 __device__ __forceinline__ void uv_of(const float* __restrict__ rec, int N, int p, int ch, float& u,
                                       float& v) {
@@ -145,13 +166,7 @@ __global__ __launch_bounds__(NT) void hist_accum_kernel(const float* __restrict_
       iy = r[p];
     }
     __syncthreads();   // previous chunk's MFMA reads are done
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      const int bin = wave * 16 + k;
-      const double bc = hp.bins[bin];
-      As[lane * LS + bin] = ok ? iy * kweight(u, bc, hp) : 0.f;
-      Bs[lane * LS + bin] = ok ? kweight(v, bc, hp) : 0.f;
-    }
+    ST_HIST_FILL(As, Bs, iy)
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < CH / 2; ++s) {
@@ -291,13 +306,7 @@ __global__ __launch_bounds__(NT) void hist_bwd_pixel_kernel(const float* __restr
     float u = 0.f, v = 0.f;
     if (ok) uv_of(r, N, p, ch, u, v);
     __syncthreads();   // previous chunk fully consumed (also orders the dH fill on the first pass)
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      const int bin = wave * 16 + k;
-      const double bc = hp.bins[bin];
-      Ku[lane * LS + bin] = ok ? kweight(u, bc, hp) : 0.f;
-      Kv[lane * LS + bin] = ok ? kweight(v, bc, hp) : 0.f;
-    }
+    ST_HIST_FILL(Ku, Kv, 1.f)
     __syncthreads();
     // this lane's MFMA column = pixel pt*32 + li of the chunk
     const int pc = pt * 32 + li;
